@@ -1,0 +1,96 @@
+/* C-ABI of the MI355X-native GNS K-step hot path (libgns_hip.so).
+ *
+ * Drop-in boundary for the reference's GNS.forward / autograd backward
+ * (LeonOrou/OPF-Graph-Neural-Solver, GNS/main.py:140-202 and the .backward() of main.py:288).
+ * Plain pointers and sizes only; every device pointer is owned by the caller (torch), nothing is
+ * allocated, synchronised or copied host<->device inside gns_forward / gns_backward, and all work is
+ * enqueued on the caller's stream, so the calls are hipGraph-capturable.  Return 0 = ok, otherwise a
+ * GNS_E* code; nothing throws across this boundary.
+ *
+ * Layouts
+ *   params / grad_params : ONE flat fp32 buffer in the reference's state_dict order
+ *                          (GNS/main.py:113-134: {phi | phi_v,phi_theta,phi_m}.k, L_theta.k, L_v.k, L_m.k;
+ *                          per block linear1.weight[h,in], linear1.bias, linear2.*, linear4.*), nn.Linear
+ *                          [out,in] row-major.  The same buffer is the RCCL all-reduce message.
+ *   buses [Bt,N,6], lines [Bt,E,7], generators [Bt,Gn,7] : the reference's column order
+ *                          (GNS/utils.py:4-13), fp32, contiguous - what utils.load_all_grids returns.
+ *   v, theta [Bt,N]; total_loss, last_loss [Bt].
+ *   Topology (f_bus, t_bus, generator buses) is shared by the whole batch (reference data:
+ *   GNS/augment_grids.py:35-53 perturbs continuous columns only).
+ */
+#ifndef GNS_HIP_H
+#define GNS_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  GNS_OK = 0,
+  GNS_EINVAL = 1,      /* null pointer / non-positive size / malformed config            */
+  GNS_EUNSUPPORTED = 2,/* (latent_dim, hidden_dim) pair has no compiled kernel           */
+  GNS_ETOPOLOGY = 3,   /* bus id out of range, or a bus id that is not a valid line index
+                          (the reference gathers per-line arrays with bus ids, main.py:41)  */
+  GNS_ESIZE = 4,       /* caller-provided buffer too small                               */
+  GNS_ELAUNCH = 5      /* HIP reported a launch error                                    */
+};
+
+/* Constructor arguments of the reference's GNS (GNS/main.py:108) plus the grid shape. */
+typedef struct gns_config {
+  int32_t n_bus;        /* N  */
+  int32_t n_line;       /* E  */
+  int32_t n_gen;        /* Gn */
+  int32_t K;            /* correction steps                    (main.py:138) */
+  int32_t latent_dim;   /* d                                   (main.py:136) */
+  int32_t hidden_dim;   /* h                                   (main.py:18)  */
+  int32_t multiple_phi; /* 0: one phi net, 1: phi_v/theta/m    (main.py:111) */
+  float   gamma;        /* loss discount                       (main.py:137) */
+} gns_config;
+
+/* Library / build identification: returns a static string such as "gns_hip 0.1 gfx950". */
+const char* gns_version(void);
+
+/* Number of fp32 parameters of GNS(latent_dim, hidden_dim, K, multiple_phi) = length of the flat
+ * params buffer (GNS/main.py:113-134).  */
+int gns_param_count(const gns_config* cfg, int64_t* count);
+
+/* 1 if a fused kernel is compiled for this (latent_dim, hidden_dim, multiple_phi), else 0. */
+int gns_config_supported(const gns_config* cfg);
+
+/* Host-side topology preparation (replaces the per-call index construction of main.py:35-36,85-86,144,153):
+ * builds, from 0-based src/dst/gen_bus HOST arrays, the destination-sorted and source-sorted CSR edge lists,
+ * the bus-id-as-line-index tuples, the adjoint incidence lists and the per-wave bus partition, into a
+ * relocatable blob of gns_topology_bytes() bytes that the caller copies to the device once per case. */
+int gns_topology_bytes(int32_t n_bus, int32_t n_line, int32_t n_gen, size_t* bytes);
+int gns_prepare_topology(int32_t n_bus, int32_t n_line, int32_t n_gen,
+                         const int32_t* src, const int32_t* dst, const int32_t* gen_bus,
+                         void* topo_host_out, size_t topo_bytes);
+
+/* Device workspace sizes for a batch of Bt grids.
+ *   fwd_bytes       : forward workspace; with save_state != 0 it also holds the K+1 per-step states the
+ *                     backward pass re-reads, and must stay untouched until gns_backward has run.
+ *   bwd_bytes       : extra scratch for gns_backward (adjoint state + per-wave gradient slabs).  */
+int gns_workspace_bytes(const gns_config* cfg, int64_t Bt, int save_state, size_t* fwd_bytes, size_t* bwd_bytes);
+
+/* GNS.forward for Bt grids (GNS/main.py:140-202).  v/theta/total_loss/last_loss are written.
+ * stream is a hipStream_t passed as void*.  */
+int gns_forward(const gns_config* cfg, const void* topo_dev, const float* params,
+                const float* buses, const float* lines, const float* generators, int64_t Bt,
+                float* v, float* theta, float* total_loss, float* last_loss,
+                void* workspace, size_t workspace_bytes, int save_state, void* stream);
+
+/* Reverse pass of the same graph (what total_loss.backward() does at GNS/main.py:288).
+ * grad_total / grad_last [Bt] and grad_v / grad_theta [Bt,N] are upstream gradients (any may be NULL = 0).
+ * grad_params (flat, state_dict order) is ACCUMULATED into (+=), like autograd does with .grad.
+ * L_m.{K-1} (and phi_m.{K-1}) receive exactly zero, matching the reference where they get no gradient. */
+int gns_backward(const gns_config* cfg, const void* topo_dev, const float* params, int64_t Bt,
+                 const void* fwd_workspace, size_t fwd_workspace_bytes,
+                 const float* grad_total, const float* grad_last, const float* grad_v, const float* grad_theta,
+                 float* grad_params, void* bwd_workspace, size_t bwd_workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNS_HIP_H */

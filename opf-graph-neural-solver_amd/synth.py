@@ -1,0 +1,142 @@
+"""Synthetic power grids in the layout the GNS hot path consumes.
+
+No case30/118/300 data exists offline and the reference's shipped case14 pickles cannot be opened
+with a non-executing loader, so every test and benchmark input is generated here.  The generator
+mirrors, vectorised over the batch and on any torch device,
+  * the perturbation ranges of the reference's ``GNS/augment_grids.py:12-53`` (r, x, b x U[0.9,1.1];
+    tau ~ U[0.8,1.2]; shift ~ U[-0.2,0.2] degrees; vg x U[0.95,1.05]; Pg ~ U[.25,.75] of the unit's
+    range; Pd x U[.5,1.5] then rescaled so that sum(Pd) == sum(Pg); Qd x U[.5,1.5]), and
+  * the column selection / per-unit normalisation of ``GNS/utils.py:17-41`` (``prepare_grid``):
+    buses [N,6] = (bus_i, type, Pd, Qd, Gs=1/baseMVA, Bs=-1/baseMVA), lines [E,7] =
+    (f_bus, t_bus, r, x, b, tau, shift[rad]), generators [Gn,7] = (bus_i, Pmax, Pmin, Pg_set, vg, qg, Pg).
+Topology is one fixed graph per case and is shared by the whole batch, exactly like the reference's
+data (``augment_grids.py`` perturbs continuous columns only).  Sizes come from ``GNS/utils.py:45-56``.
+case14 uses the public IEEE 14-bus test system as its base; the larger cases are case-SHAPED random
+connected graphs with contiguous bus ids (the real case300 has non-contiguous ids, which the reference's
+``bus_id - 1`` indexing cannot address).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+CASE_SHAPES = {14: (14, 20, 5), 30: (30, 41, 6), 118: (118, 186, 54), 300: (300, 411, 69)}
+BASE_MVA = 100.0
+
+# IEEE 14-bus test system (public data): from, to, r, x, b
+_IEEE14_BRANCH = [
+    (1, 2, 0.01938, 0.05917, 0.0528), (1, 5, 0.05403, 0.22304, 0.0492), (2, 3, 0.04699, 0.19797, 0.0438),
+    (2, 4, 0.05811, 0.17632, 0.0340), (2, 5, 0.05695, 0.17388, 0.0346), (3, 4, 0.06701, 0.17103, 0.0128),
+    (4, 5, 0.01335, 0.04211, 0.0), (4, 7, 0.0, 0.20912, 0.0), (4, 9, 0.0, 0.55618, 0.0),
+    (5, 6, 0.0, 0.25202, 0.0), (6, 11, 0.09498, 0.19890, 0.0), (6, 12, 0.12291, 0.25581, 0.0),
+    (6, 13, 0.06615, 0.13027, 0.0), (7, 8, 0.0, 0.17615, 0.0), (7, 9, 0.0, 0.11001, 0.0),
+    (9, 10, 0.03181, 0.08450, 0.0), (9, 14, 0.12711, 0.27038, 0.0), (10, 11, 0.08205, 0.19207, 0.0),
+    (12, 13, 0.22092, 0.19988, 0.0), (13, 14, 0.17093, 0.34802, 0.0)]
+_IEEE14_PD = [0.0, 21.7, 94.2, 47.8, 7.6, 11.2, 0.0, 0.0, 29.5, 9.0, 3.5, 6.1, 13.5, 14.9]
+_IEEE14_QD = [0.0, 12.7, 19.0, -3.9, 1.6, 7.5, 0.0, 0.0, 16.6, 5.8, 1.8, 1.6, 5.8, 5.0]
+# bus, Pg, Qg, Vg, Pmax, Pmin
+_IEEE14_GEN = [(1, 232.4, -16.9, 1.06, 332.4, 0.0), (2, 40.0, 42.4, 1.045, 140.0, 0.0), (3, 0.0, 23.4, 1.01, 100.0, 0.0),
+               (6, 0.0, 12.2, 1.07, 100.0, 0.0), (8, 0.0, 17.4, 1.09, 100.0, 0.0)]
+
+
+def base_case(case_nr: int) -> dict:
+    """Un-augmented base quantities (float64 numpy, MW / MVAr / p.u. like a PYPOWER case)."""
+    if case_nr not in CASE_SHAPES:
+        raise ValueError(f'unknown case {case_nr}; known: {sorted(CASE_SHAPES)}')
+    n, e, gn = CASE_SHAPES[case_nr]
+    if case_nr == 14:
+        br = np.array(_IEEE14_BRANCH, dtype=np.float64)
+        gen = np.array(_IEEE14_GEN, dtype=np.float64)
+        return dict(f_bus=br[:, 0].astype(np.int64), t_bus=br[:, 1].astype(np.int64), r=br[:, 2], x=br[:, 3], b=br[:, 4],
+                    Pd=np.array(_IEEE14_PD), Qd=np.array(_IEEE14_QD), gen_bus=gen[:, 0].astype(np.int64),
+                    Pg=gen[:, 1], Qg=gen[:, 2], Vg=gen[:, 3], Pmax=gen[:, 4], Pmin=gen[:, 5])
+    rng = np.random.default_rng(1000 + case_nr)
+    # random spanning tree over a random bus order, then extra lines (parallel lines allowed)
+    order = rng.permutation(n) + 1
+    f, t = [], []
+    for i in range(1, n):
+        a, b_ = int(order[rng.integers(0, i)]), int(order[i])
+        if rng.random() < 0.5:
+            a, b_ = b_, a
+        f.append(a); t.append(b_)
+    while len(f) < e:
+        a, b_ = (int(z) for z in rng.integers(1, n + 1, size=2))
+        if a != b_:
+            f.append(a); t.append(b_)
+    perm = rng.permutation(e)
+    f_bus, t_bus = np.array(f, dtype=np.int64)[perm], np.array(t, dtype=np.int64)[perm]
+    gen_bus = np.sort(rng.choice(n, size=gn, replace=False) + 1).astype(np.int64)
+    pmax = rng.uniform(100.0, 350.0, size=gn)
+    load = rng.uniform(0.0, 1.0, size=n) * (rng.random(n) < 0.8)
+    return dict(f_bus=f_bus, t_bus=t_bus, r=rng.uniform(0.0, 0.25, size=e) * (rng.random(e) < 0.85),
+                x=rng.uniform(0.04, 0.6, size=e), b=rng.uniform(0.0, 0.06, size=e) * (rng.random(e) < 0.7),
+                Pd=load * pmax.sum() * 0.5 / max(load.sum(), 1e-9), Qd=rng.uniform(-5.0, 25.0, size=n),
+                gen_bus=gen_bus, Pg=pmax * 0.5, Qg=rng.uniform(-20.0, 50.0, size=gn), Vg=rng.uniform(1.0, 1.09, size=gn),
+                Pmax=pmax, Pmin=np.zeros(gn))
+
+
+def case_topology(case_nr: int):
+    """(f_bus[E], t_bus[E], gen_bus[Gn]) as 1-based int64 numpy arrays."""
+    c = base_case(case_nr)
+    return c['f_bus'], c['t_bus'], c['gen_bus']
+
+
+def synth_grids(case_nr: int, batch: int, seed: int = 0, device='cpu', load_scale: float = 1.0, augment: bool = True):
+    """Return (buses[B,N,6], lines[B,E,7], generators[B,Gn,7]) float32 on ``device``.
+
+    ``load_scale`` multiplies Pd after balancing; < ~0.6 drives the lambda < 0.5 branch of
+    ``global_active_compensation`` (GNS/main.py:48,54), which balanced random-weight grids never reach.
+    """
+    c = base_case(case_nr)
+    n, e, gn = CASE_SHAPES[case_nr]
+    dev = torch.device(device)
+    g = torch.Generator(device=dev).manual_seed(int(seed))
+    f32 = dict(dtype=torch.float32, device=dev)
+
+    def tens(a):
+        return torch.as_tensor(np.asarray(a, dtype=np.float32), device=dev)
+
+    def uni(lo, hi, *shape):
+        return torch.rand(shape, generator=g, **f32) * (hi - lo) + lo
+
+    one = lambda *shape: torch.ones(shape, **f32)
+    amp = (lambda lo, hi, *s: uni(lo, hi, *s)) if augment else (lambda lo, hi, *s: one(*s))
+    r = tens(c['r']) * amp(0.9, 1.1, batch, e)
+    x = tens(c['x']) * amp(0.9, 1.1, batch, e)
+    b = tens(c['b']) * amp(0.9, 1.1, batch, e)
+    tau = uni(0.8, 1.2, batch, e) if augment else one(batch, e)
+    shift_deg = uni(-0.2, 0.2, batch, e) if augment else torch.zeros(batch, e, **f32)
+    vg = tens(c['Vg']) * amp(0.95, 1.05, batch, gn)
+    pmax, pmin = tens(c['Pmax']).expand(batch, gn), tens(c['Pmin']).expand(batch, gn)
+    span = pmax - pmin
+    pg = (pmin + span * 0.25) + uni(0.0, 1.0, batch, gn) * (span * 0.75 - (pmin + span * 0.25)) if augment \
+        else tens(c['Pg']).expand(batch, gn)
+    pd = tens(c['Pd']) * amp(0.5, 1.5, batch, n)
+    pd = pd * (pg.sum(dim=1, keepdim=True) / pd.sum(dim=1, keepdim=True).clamp_min(1e-9)) * load_scale
+    qd = tens(c['Qd']) * amp(0.5, 1.5, batch, n)
+    qg = tens(c['Qg']).expand(batch, gn)
+
+    buses = torch.zeros(batch, n, 6, **f32)
+    buses[:, :, 0] = torch.arange(1, n + 1, **f32)
+    buses[:, :, 1] = 1.0
+    buses[:, :, 2] = pd / BASE_MVA
+    buses[:, :, 3] = qd / BASE_MVA
+    buses[:, :, 4] = 1.0 / BASE_MVA
+    buses[:, :, 5] = -1.0 / BASE_MVA
+    lines = torch.zeros(batch, e, 7, **f32)
+    lines[:, :, 0] = tens(c['f_bus'])
+    lines[:, :, 1] = tens(c['t_bus'])
+    lines[:, :, 2], lines[:, :, 3], lines[:, :, 4] = r, x, b
+    lines[:, :, 5] = torch.where(tau == 0, torch.ones_like(tau), tau)
+    lines[:, :, 6] = shift_deg * (math.pi / 180.0)
+    gens = torch.zeros(batch, gn, 7, **f32)
+    gens[:, :, 0] = tens(c['gen_bus'])
+    gens[:, :, 1] = pmax / BASE_MVA
+    gens[:, :, 2] = pmin / BASE_MVA
+    gens[:, :, 3] = pg / BASE_MVA
+    gens[:, :, 4] = vg
+    gens[:, :, 5] = qg / BASE_MVA
+    gens[:, :, 6] = pg / BASE_MVA
+    return buses, lines, gens
