@@ -1,0 +1,42 @@
+"""Shared helpers for the parity tests."""
+import glob
+import os
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def golden_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, '*.npz')))
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def cfg_of(g):
+    return dict(latent_dim=int(g['latent_dim']), hidden_dim=int(g['hidden_dim']), K=int(g['K']),
+                gamma=float(g['gamma']), multiple_phi=bool(int(g['multiple_phi'])))
+
+
+def rel_err(a, b):
+    """max|a-b| / max|b| - the per-tensor measure of SURVEY section 8c (theta straddles 0)."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30))
+
+
+def assert_close(a, b, rel, abs_floor=1e-6, what=''):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, f'{what}: shape {a.shape} vs {b.shape}'
+    assert np.all(np.isfinite(a)), f'{what}: non-finite values'
+    tol = abs_floor + rel * np.max(np.abs(b))
+    worst = float(np.max(np.abs(a - b)))
+    assert worst <= tol, f'{what}: max|diff|={worst:.3e} > tol={tol:.3e} (rel_err={rel_err(a, b):.3e})'
+
+
+def t(x):
+    return torch.as_tensor(np.asarray(x))
