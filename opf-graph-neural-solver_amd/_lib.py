@@ -1,0 +1,53 @@
+"""ctypes binding of libgns_hip.so (include/gns_hip.h).  Fails loudly when the library is missing."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+GNS_ERRORS = {1: 'GNS_EINVAL (bad argument)', 2: 'GNS_EUNSUPPORTED (no kernel for this latent_dim/hidden_dim/K)',
+              3: 'GNS_ETOPOLOGY (bus id out of range or not a valid line index)', 4: 'GNS_ESIZE (buffer too small)',
+              5: 'GNS_ELAUNCH (HIP launch error)'}
+
+
+class GnsConfig(ctypes.Structure):
+    _fields_ = [('n_bus', ctypes.c_int32), ('n_line', ctypes.c_int32), ('n_gen', ctypes.c_int32), ('K', ctypes.c_int32),
+                ('latent_dim', ctypes.c_int32), ('hidden_dim', ctypes.c_int32), ('multiple_phi', ctypes.c_int32),
+                ('gamma', ctypes.c_float)]
+
+
+def library_path():
+    return os.path.join(_HERE, 'libgns_hip.so')
+
+
+def load_library():
+    """Load (once) and type the C-ABI.  Raises OSError with build instructions if the .so is absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise OSError(f'{path} not found: build it with `make -C {os.path.join(_HERE, "csrc")}` '
+                      '(hipcc --offload-arch=gfx950) or `python -c "import __graft_entry__ as g; g.build()"`. '
+                      'There is no CPU fallback for the GNS hot path.')
+    lib = ctypes.CDLL(path)
+    vp, i32, i64, sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
+    cfgp = ctypes.POINTER(GnsConfig)
+    lib.gns_version.restype = ctypes.c_char_p
+    lib.gns_version.argtypes = []
+    lib.gns_param_count.argtypes = [cfgp, ctypes.POINTER(i64)]
+    lib.gns_config_supported.argtypes = [cfgp]
+    lib.gns_topology_bytes.argtypes = [i32, i32, i32, ctypes.POINTER(sz)]
+    lib.gns_prepare_topology.argtypes = [i32, i32, i32, vp, vp, vp, vp, sz]
+    lib.gns_workspace_bytes.argtypes = [cfgp, i64, ctypes.c_int, ctypes.POINTER(sz), ctypes.POINTER(sz)]
+    lib.gns_forward.argtypes = [cfgp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, sz, ctypes.c_int, vp]
+    lib.gns_backward.argtypes = [cfgp, vp, vp, i64, vp, sz, vp, vp, vp, vp, vp, vp, sz, vp]
+    for f in ('gns_param_count', 'gns_config_supported', 'gns_topology_bytes', 'gns_prepare_topology',
+              'gns_workspace_bytes', 'gns_forward', 'gns_backward'):
+        getattr(lib, f).restype = ctypes.c_int
+    _LIB = lib
+    return lib
+
+
+EXPORTS = ('gns_version', 'gns_param_count', 'gns_config_supported', 'gns_topology_bytes', 'gns_prepare_topology',
+           'gns_workspace_bytes', 'gns_forward', 'gns_backward')

@@ -1,0 +1,83 @@
+// C-ABI entry points (include/gns_hip.h).  Host code only: validates, lays out the workspace and enqueues
+// kernels on the caller's stream.  No allocation, no synchronisation, no host<->device copies.
+#include <cmath>
+#include <cstring>
+#include "gns_kernels.h"
+
+static bool dims_supported(int d, int h) {
+#define GNS_CASE(DD, HH) if (d == DD && h == HH) return true;
+  GNS_FOR_EACH_DIMS(GNS_CASE)
+#undef GNS_CASE
+  return false;
+}
+
+static int check_cfg(const gns_config* c) {
+  if (!c) return GNS_EINVAL;
+  if (c->n_bus <= 0 || c->n_line <= 0 || c->n_gen < 0 || c->K <= 0 || c->latent_dim <= 0 || c->hidden_dim <= 0) return GNS_EINVAL;
+  if (c->multiple_phi != 0 && c->multiple_phi != 1) return GNS_EINVAL;
+  return GNS_OK;
+}
+
+extern "C" const char* gns_version(void) { return "gns_hip 0.1 gfx950"; }
+
+extern "C" int gns_param_count(const gns_config* cfg, int64_t* count) {
+  if (!cfg || !count || cfg->K <= 0 || cfg->latent_dim <= 0 || cfg->hidden_dim <= 0) return GNS_EINVAL;
+  GnsFamilies f; gns_families(cfg->latent_dim, cfg->hidden_dim, cfg->K, cfg->multiple_phi, &f);
+  *count = f.flat_total;
+  return GNS_OK;
+}
+
+extern "C" int gns_config_supported(const gns_config* cfg) {
+  if (check_cfg(cfg) != GNS_OK) return 0;
+  return dims_supported(cfg->latent_dim, cfg->hidden_dim) && cfg->K <= GNS_MAX_K ? 1 : 0;
+}
+
+extern "C" int gns_workspace_bytes(const gns_config* cfg, int64_t Bt, int save_state, size_t* fwd_bytes, size_t* bwd_bytes) {
+  int rc = check_cfg(cfg);
+  if (rc != GNS_OK) return rc;
+  if (Bt <= 0) return GNS_EINVAL;
+  GnsFwdLayout L;
+  gns_fwd_layout(cfg->n_bus, cfg->n_line, cfg->latent_dim, cfg->hidden_dim, cfg->K, cfg->multiple_phi, Bt, save_state, &L);
+  if (fwd_bytes) *fwd_bytes = L.total;
+  if (bwd_bytes) {
+    GnsBwdLayout B;
+    gns_bwd_layout(cfg->n_bus, cfg->n_line, cfg->latent_dim, cfg->hidden_dim, cfg->K, cfg->multiple_phi, Bt, &B);
+    *bwd_bytes = B.total;
+  }
+  return GNS_OK;
+}
+
+extern "C" int gns_forward(const gns_config* cfg, const void* topo_dev, const float* params, const float* buses,
+                           const float* lines, const float* generators, int64_t Bt, float* v, float* theta,
+                           float* total_loss, float* last_loss, void* workspace, size_t workspace_bytes, int save_state,
+                           void* stream) {
+  int rc = check_cfg(cfg);
+  if (rc != GNS_OK) return rc;
+  if (!topo_dev || !params || !buses || !lines || !generators || !v || !theta || !total_loss || !last_loss || !workspace || Bt <= 0)
+    return GNS_EINVAL;
+  if (!dims_supported(cfg->latent_dim, cfg->hidden_dim) || cfg->K > GNS_MAX_K) return GNS_EUNSUPPORTED;
+  const int N = cfg->n_bus, E = cfg->n_line, Gn = cfg->n_gen, K = cfg->K, d = cfg->latent_dim, h = cfg->hidden_dim;
+  GnsFwdLayout L;
+  gns_fwd_layout(N, E, d, h, K, cfg->multiple_phi, Bt, save_state, &L);
+  if (workspace_bytes < L.total) return GNS_ESIZE;
+  GnsFamilies fam; gns_families(d, h, K, cfg->multiple_phi, &fam);
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  float* pt = (float*)(ws + L.off_pt);
+  float* pn = (float*)(ws + L.off_pn);
+  float* pin = (float*)(ws + L.off_in);
+  rc = gns_launch_pack_params(params, pt, pn, fam, K, h, st);
+  if (rc != GNS_OK) return rc;
+  rc = gns_launch_pack_inputs((const int*)topo_dev, buses, lines, generators, pin, N, E, Gn, Bt, L.groups, st);
+  if (rc != GNS_OK) return rc;
+  GnsFwdArgs A;
+  std::memset(&A, 0, sizeof(A));
+  A.topo = (const int*)topo_dev; A.pt = pt; A.in = pin;
+  A.state = (float*)(ws + L.off_state); A.lam = (float*)(ws + L.off_lam);
+  A.v_out = v; A.theta_out = theta; A.total_out = total_loss; A.last_out = last_loss;
+  for (int i = 0; i < fam.nfam; ++i) { A.t_off[i] = fam.t_off[i]; A.t_sz[i] = fam.t_sz[i]; }
+  for (int k = 0; k < K; ++k) A.gw[k] = (float)std::pow((double)cfg->gamma, (double)(K - k));   // main.py:198
+  A.Bt = Bt; A.G = L.groups; A.N = N; A.E = E; A.K = K; A.save = save_state ? 1 : 0; A.zero = 0;
+  A.part_idx = gns_part_index(GNS_FWD_THREADS / 64);
+  return gns_launch_forward(d, h, cfg->multiple_phi, A, GNS_FWD_THREADS, st);
+}

@@ -1,0 +1,142 @@
+// Shared host/device definitions for the MI355X GNS hot path (gfx950 only).
+//
+// Execution model: one LANE owns one grid, one 64-lane wave owns 64 grids, and the
+// waves of a workgroup split the BUSES of those 64 grids.  Topology is identical for every grid of a
+// batch, so every bus/line index is wave-uniform: indices and MLP weights travel through the scalar
+// unit (s_load -> SGPR operands of v_pk_fma_f32), per-grid data is laid out [row][64 lanes][4 floats]
+// so that every vector access is one fully coalesced 1 KiB transaction.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define GNS_HD __host__ __device__
+#else
+#define GNS_HD
+#endif
+
+#define GNS_LANES 64
+#define GNS_TOPO_MAGIC 0x474e5331  // "GNS1"
+#define GNS_NPART 5                // bus partitions are stored for 1,2,4,8,16 waves per workgroup
+#define GNS_MAXW 16
+
+// ---- topology blob: int32 words; hdr[i] below are word offsets from the blob start ----------------
+enum {
+  TH_MAGIC = 0, TH_N, TH_E, TH_GN,
+  TH_IN_PTR,    // [N+1] CSR over destination bus (stable in line order)            main.py:153
+  TH_IN_EID,    // [E]   original line index of in-edge p
+  TH_IN_SRC,    // [E]   s = src[e]
+  TH_IN_A,      // [E]   a = src[line s]   } the reference gathers delta_ij[src] : line NUMBER s=src[e]
+  TH_IN_B,      // [E]   b = dst[line s]   } (main.py:41,68,91,98)
+  TH_OUT_PTR,   // [N+1] CSR over source bus
+  TH_OUT_EID,   // [E]
+  TH_OUT_DST,   // [E]   t = dst[e]
+  TH_OUT_C,     // [E]   c = src[line t]   } delta_ji[dst] : line NUMBER t=dst[e] (main.py:70-72,92,99)
+  TH_OUT_D,     // [E]   d = dst[line t]
+  TH_IS_GEN,    // [N]   1 if a generator sits on the bus (main.py:184-185)
+  TH_GEN_PTR,   // [N+1] generators per bus, in generator order
+  TH_GEN_IDX,   // [Gn]
+  TH_PART,      // [GNS_NPART][GNS_MAXW+1] bus ranges per wave, balanced by work
+  TH_P2Q,       // [E]   position in the source-sorted list of in-edge p
+  TH_Q2P,       // [E]
+  TH_EPART,     // [GNS_NPART][GNS_MAXW+1] ranges of in-edge positions per wave (backward, edge-centric)
+  TH_INCD_PTR,  // [N+1] incidence list of the delta adjoints (backward)
+  TH_INCD,      // [4E]  p*4 + code ; code 0:+dbar 1:-dbar 2:+dbar' 3:-dbar'
+  TH_TOTAL,     // blob length in words
+  TH_HDR_WORDS = 32
+};
+
+// ---- packed per-grid inputs: float4 rows, [group][row][lane] ---------------------------------------
+// bus n    : rows 3n..3n+2      (Pd,Qd,Gs,Bs) (Pmin,Pset,Pmax,v0) (dp0,dq0,0,0)
+// in-edge p: rows 3N+3p..+2     (r,x,b,tau) (shift, y_s,tau_s,sh_s) (b_s,0,0,0)      s = src[e] used as LINE number
+// out-edge q: row 3N+3E+q       (y_t,tau_t,sh_t,b_t)                                 t = dst[e] used as LINE number
+// grid     : row 3N+4E          (sumPd, sumPset, sumPmin, sumPmax)
+GNS_HD static inline int64_t gns_in_rows(int N, int E) { return 3LL * N + 4LL * E + 1; }
+
+static inline int gns_part_index(int waves) {
+  switch (waves) { case 1: return 0; case 2: return 1; case 4: return 2; case 8: return 3; case 16: return 4; default: return -1; }
+}
+
+// Parameter block geometry ------------------------------------------------------------------------
+// flat (state_dict) block of one LearningBlock: W1[h][in] b1[h] W2[h][h] b2[h] W4[out][h] b4[out]
+static inline int64_t gns_flat_block(int in, int h, int out) { return (int64_t)in * h + h + (int64_t)h * h + h + (int64_t)out * h + out; }
+// T-stream (forward): W1t[in][h] b1[h] W2t[h][h] b2[h] W4t[h][outp] b4[outp], padded to 16 floats
+static inline int64_t gns_t_block(int in, int h, int out) { int op = out + (out & 1); int64_t t = (int64_t)in * h + h + (int64_t)h * h + h + (int64_t)h * op + op; return (t + 15) / 16 * 16; }
+// N-stream (backward data path): W4n[outp][h] W2n[h][h] W1n[h][inp], padded to 16 floats
+static inline int64_t gns_n_block(int in, int h, int out) { int op = out + (out & 1); int ip = in + (in & 1); int64_t t = (int64_t)op * h + (int64_t)h * h + (int64_t)h * ip; return (t + 15) / 16 * 16; }
+
+struct GnsFamilies {   // per network family (phi*, L_theta, L_v, L_m) in state_dict order
+  int nfam;            // 4 (single phi) or 6
+  int in[6], out[6];
+  int64_t flat_off[6], t_off[6], n_off[6];    // offset of block k=0 of the family
+  int64_t flat_sz[6], t_sz[6], n_sz[6];       // per-k block size
+  int64_t flat_total, t_total, n_total;
+};
+
+static inline void gns_families(int d, int h, int K, int multi, GnsFamilies* f) {
+  f->nfam = multi ? 6 : 4;
+  int nphi = multi ? 3 : 1;
+  int64_t fo = 0, to = 0, no = 0;
+  for (int i = 0; i < f->nfam; ++i) {
+    bool is_phi = i < nphi;
+    f->in[i] = is_phi ? d + 5 : 4 + 2 * d;
+    f->out[i] = is_phi ? (multi ? d : 1) : (i == f->nfam - 1 ? d : 1);
+    f->flat_sz[i] = gns_flat_block(f->in[i], h, f->out[i]);
+    f->t_sz[i] = gns_t_block(f->in[i], h, f->out[i]);
+    f->n_sz[i] = gns_n_block(f->in[i], h, f->out[i]);
+    f->flat_off[i] = fo; f->t_off[i] = to; f->n_off[i] = no;
+    fo += f->flat_sz[i] * K; to += f->t_sz[i] * K; no += f->n_sz[i] * K;
+  }
+  f->flat_total = fo; f->t_total = to + 64; f->n_total = no + 64;   // +64: the 16-float chunk loader may read past the end
+}
+
+// ---- forward workspace layout (byte offsets, 256-B aligned) -----------------------------------------
+struct GnsFwdLayout {
+  int64_t groups;        // ceil(Bt/64)
+  int64_t mq;            // float4 rows holding the latent vector: ceil(d/4)
+  int64_t rows_bus;      // 1 + mq
+  int64_t slots;         // K+1 when the state is saved for backward, else 1
+  size_t off_pt, off_pn, off_in, off_lam, off_state, total;
+};
+
+static inline size_t gns_align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static inline void gns_fwd_layout(int N, int E, int d, int h, int K, int multi, int64_t Bt, int save, GnsFwdLayout* L) {
+  GnsFamilies f; gns_families(d, h, K, multi, &f);
+  L->groups = (Bt + GNS_LANES - 1) / GNS_LANES;
+  L->mq = (d + 3) / 4;
+  L->rows_bus = 1 + L->mq;
+  L->slots = save ? K + 1 : 1;
+  size_t o = 0;
+  L->off_pt = o;    o = gns_align256(o + (size_t)f.t_total * 4);
+  L->off_pn = o;    o = gns_align256(o + (size_t)f.n_total * 4);
+  L->off_in = o;    o = gns_align256(o + (size_t)L->groups * gns_in_rows(N, E) * GNS_LANES * 16);
+  L->off_lam = o;   o = gns_align256(o + (size_t)K * L->groups * GNS_LANES * 8);
+  L->off_state = o; o = gns_align256(o + (size_t)L->slots * L->groups * N * L->rows_bus * GNS_LANES * 16);
+  L->total = o;
+}
+
+// ---- backward workspace layout ------------------------------------------------------------------------
+struct GnsBwdLayout {
+  int64_t groups, mq, rows_bus;
+  int64_t slab_floats;     // per-wave gradient slab: one float per flat parameter
+  int64_t nslab;           // number of slabs (workgroups x waves)
+  size_t off_adj, off_slots, off_slab, total;
+};
+#define GNS_BWD_MAX_WG 512   // persistent backward workgroups (each loops over grid groups)
+
+static inline void gns_bwd_layout(int N, int E, int d, int h, int K, int multi, int64_t Bt, GnsBwdLayout* B) {
+  GnsFamilies f; gns_families(d, h, K, multi, &f);
+  B->groups = (Bt + GNS_LANES - 1) / GNS_LANES;
+  B->mq = (d + 3) / 4;
+  B->rows_bus = 1 + B->mq;
+  B->slab_floats = (f.flat_total + 63) / 64 * 64;
+  int64_t wg = B->groups < GNS_BWD_MAX_WG ? B->groups : GNS_BWD_MAX_WG;
+  B->nslab = wg * GNS_MAXW;
+  size_t o = 0;
+  B->off_adj = o;   o = gns_align256(o + (size_t)B->groups * N * B->rows_bus * GNS_LANES * 16);   // (vbar,thbar,dpbar,-) + mbar
+  B->off_slots = o; o = gns_align256(o + (size_t)B->groups * 6 * E * GNS_LANES * 4);               // 6 adjoint planes per line
+  B->off_slab = o;  o = gns_align256(o + (size_t)B->nslab * B->slab_floats * 4);
+  B->total = o;
+}

@@ -1,0 +1,174 @@
+// Device-side building blocks shared by the forward and backward kernels (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include "gns_common.h"
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+// address space 4 (constant): loads with a wave-uniform address become s_load (scalar cache -> SGPRs)
+typedef const __attribute__((address_space(4))) float* cfp;
+typedef const __attribute__((address_space(4))) int* cip;
+typedef const __attribute__((address_space(4))) f16v* cf16p;
+
+#define GNS_LEAKY 0.01f   // torch.nn.LeakyReLU default slope (GNS/main.py:23)
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// Walk NF (even) consecutive floats at a wave-uniform address in pairs: f(ic<w>, {p[w],p[w+1]}), w = 0,2,...
+// 16-float chunks are fetched with s_load_dwordx16 one chunk ahead of their use; the scheduling
+// barriers keep hipcc from hoisting every load to the top (which spills SGPRs through v_writelane).
+// A zero the optimiser cannot see through (SGPR-constrained asm output = wave-uniform): added to a weight
+// pointer it pins the s_loads to the place where the weights are used.  Without it LICM hoists all ~600
+// loads of a LearningBlock out of the bus / line loops and spills the SGPRs through v_writelane.
+__device__ __forceinline__ int opaque_zero() {
+  int z = 0;
+  asm volatile("" : "+s"(z));
+  return z;
+}
+
+template <int NF, class F>
+__device__ __forceinline__ void stream_pairs(cfp p, F&& f) {
+  constexpr int NCH = (NF + 15) / 16;
+  p += opaque_zero();
+  f16v bufA, bufB;
+  bufA = *(cf16p)(p);
+  static_for<0, NCH>([&](auto c_) {
+    constexpr int c = decltype(c_)::value;
+    f16v& cur = (c & 1) ? bufB : bufA;
+    f16v& nxt = (c & 1) ? bufA : bufB;
+    if constexpr (c + 1 < NCH) nxt = *(cf16p)(p + 16 * (c + 1));
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, 8>([&](auto t_) {
+      constexpr int t = decltype(t_)::value;
+      constexpr int w = c * 16 + 2 * t;
+      if constexpr (w < NF) f(std::integral_constant<int, w>{}, f2{cur[2 * t], cur[2 * t + 1]});
+    });
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
+__device__ __forceinline__ f2 splat(float x) { return f2{x, x}; }
+__device__ __forceinline__ f2 lrelu2(f2 z) { return __builtin_elementwise_max(z, z * GNS_LEAKY); }
+template <int I, int HP>
+__device__ __forceinline__ float lane_of(const f2 (&a)[HP]) { return (I & 1) ? a[I / 2].y : a[I / 2].x; }
+// derivative of LeakyReLU from its OUTPUT (sign-preserving): 1 where a > 0 else slope
+__device__ __forceinline__ f2 dlrelu2(f2 a) { return f2{a.x > 0.f ? 1.f : GNS_LEAKY, a.y > 0.f ? 1.f : GNS_LEAKY}; }
+
+// LearningBlock forward (GNS/main.py:25-31) from the T-stream:
+//   W1t[IN][H] b1[H] W2t[H][H] b2[H] W4t[H][OUTP] b4[OUTP]
+// Two output neurons of one input share an aligned SGPR pair: v_pk_fma_f32 acc2, s[pair], x_i(bcast).
+template <int IN, int H, int OUTP>
+struct TLay {
+  static constexpr int oW1 = 0, ob1 = IN * H, oW2 = ob1 + H, ob2 = oW2 + H * H, oW4 = ob2 + H, ob4 = oW4 + H * OUTP,
+                       total = ob4 + OUTP;
+};
+
+template <int IN, int H, int OUTP>
+__device__ __forceinline__ void mlp_fwd(cfp blk, const float (&x)[IN], f2 (&a1)[H / 2], f2 (&a2)[H / 2], f2 (&y)[OUTP / 2]) {
+  using B = TLay<IN, H, OUTP>;
+  static_assert(H % 2 == 0 && OUTP % 2 == 0, "pairs");
+  stream_pairs<B::total>(blk, [&](auto w_, f2 s) {
+    constexpr int w = decltype(w_)::value;
+    if constexpr (w < B::ob1) {
+      constexpr int i = w / H, j = (w % H) / 2;
+      a1[j] = (i == 0) ? s * splat(x[0]) : __builtin_elementwise_fma(s, splat(x[i]), a1[j]);
+    } else if constexpr (w < B::oW2) {
+      constexpr int j = (w - B::ob1) / 2;
+      a1[j] = lrelu2(a1[j] + s);
+    } else if constexpr (w < B::ob2) {
+      constexpr int q = w - B::oW2, i = q / H, j = (q % H) / 2;
+      const f2 xi = splat(lane_of<i>(a1));
+      a2[j] = (i == 0) ? s * xi : __builtin_elementwise_fma(s, xi, a2[j]);
+    } else if constexpr (w < B::oW4) {
+      constexpr int j = (w - B::ob2) / 2;
+      a2[j] = lrelu2(a2[j] + s);
+    } else if constexpr (w < B::ob4) {
+      constexpr int q = w - B::oW4, i = q / OUTP, j = (q % OUTP) / 2;
+      const f2 xi = splat(lane_of<i>(a2));
+      y[j] = (i == 0) ? s * xi : __builtin_elementwise_fma(s, xi, y[j]);
+    } else {
+      constexpr int j = (w - B::ob4) / 2;
+      y[j] += s;
+    }
+  });
+}
+
+// LearningBlock backward, data path, from the N-stream: W4n[OUTP][H] W2n[H][H] W1n[H][INP]
+//   g3 = dL/dy.  Produces g2, g1 = dL/d(pre-activation of layer 2, 1) and gx = dL/dx[0..NX).
+template <int IN, int H, int OUTP>
+struct NLay {
+  static constexpr int INP = IN + (IN & 1);
+  static constexpr int oW4 = 0, oW2 = OUTP * H, oW1 = oW2 + H * H, total = oW1 + H * INP;
+};
+
+template <int IN, int H, int OUTP, int NX>
+__device__ __forceinline__ void mlp_bwd(cfp blk, const f2 (&a1)[H / 2], const f2 (&a2)[H / 2], const f2 (&g3)[OUTP / 2],
+                                        f2 (&g2)[H / 2], f2 (&g1)[H / 2], f2 (&gx)[NX / 2]) {
+  using B = NLay<IN, H, OUTP>;
+  static_assert(NX % 2 == 0 && NX <= B::INP, "NX");
+  stream_pairs<B::total>(blk, [&](auto w_, f2 s) {
+    constexpr int w = decltype(w_)::value;
+    if constexpr (w < B::oW2) {
+      constexpr int j = w / H, i = (w % H) / 2;
+      const f2 gj = splat(lane_of<j>(g3));
+      g2[i] = (j == 0) ? s * gj : __builtin_elementwise_fma(s, gj, g2[i]);
+    } else if constexpr (w < B::oW1) {
+      constexpr int q = w - B::oW2, j = q / H, i = (q % H) / 2;
+      if constexpr (q == 0) {
+        static_for<0, H / 2>([&](auto u_) { constexpr int u = decltype(u_)::value; g2[u] = g2[u] * dlrelu2(a2[u]); });
+      }
+      const f2 gj = splat(lane_of<j>(g2));
+      g1[i] = (j == 0) ? s * gj : __builtin_elementwise_fma(s, gj, g1[i]);
+    } else {
+      constexpr int q = w - B::oW1, j = q / B::INP, i = (q % B::INP) / 2;
+      if constexpr (q == 0) {
+        static_for<0, H / 2>([&](auto u_) { constexpr int u = decltype(u_)::value; g1[u] = g1[u] * dlrelu2(a1[u]); });
+      }
+      if constexpr (2 * i < NX) {
+        const f2 gj = splat(lane_of<j>(g1));
+        gx[i] = (j == 0) ? s * gj : __builtin_elementwise_fma(s, gj, gx[i]);
+      }
+    }
+  });
+}
+
+// float4-row addressing: [row][lane] with 16 B per lane -> every wave access is one contiguous 1 KiB
+__device__ __forceinline__ const f4* row_ptr(const float* base, long long row, int lane) {
+  return reinterpret_cast<const f4*>(base) + row * GNS_LANES + lane;
+}
+__device__ __forceinline__ f4* row_ptr(float* base, long long row, int lane) {
+  return reinterpret_cast<f4*>(base) + row * GNS_LANES + lane;
+}
+
+// D floats stored as ceil(D/4) consecutive float4 rows (unused tail components are written as 0)
+template <int D>
+__device__ __forceinline__ void load_vec(const float* base, long long row, int lane, float (&m)[D]) {
+  static_for<0, (D + 3) / 4>([&](auto q_) {
+    constexpr int q = decltype(q_)::value;
+    const f4 t = *row_ptr(base, row + q, lane);
+    if constexpr (4 * q + 0 < D) m[4 * q + 0] = t.x;
+    if constexpr (4 * q + 1 < D) m[4 * q + 1] = t.y;
+    if constexpr (4 * q + 2 < D) m[4 * q + 2] = t.z;
+    if constexpr (4 * q + 3 < D) m[4 * q + 3] = t.w;
+  });
+}
+template <int D>
+__device__ __forceinline__ void store_vec(float* base, long long row, int lane, const float (&m)[D]) {
+  static_for<0, (D + 3) / 4>([&](auto q_) {
+    constexpr int q = decltype(q_)::value;
+    f4 t = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (4 * q + 0 < D) t.x = m[4 * q + 0];
+    if constexpr (4 * q + 1 < D) t.y = m[4 * q + 1];
+    if constexpr (4 * q + 2 < D) t.z = m[4 * q + 2];
+    if constexpr (4 * q + 3 < D) t.w = m[4 * q + 3];
+    *row_ptr(base, row + q, lane) = t;
+  });
+}

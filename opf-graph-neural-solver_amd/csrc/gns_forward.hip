@@ -1,0 +1,329 @@
+// Fused forward of the GNS K-step loop (GNS/main.py:140-202) for gfx950, plus the two layout kernels
+// in front of it.  One launch runs all K steps of 64*gridDim.x grids.
+#include "gns_device.h"
+#include "gns_kernels.h"
+
+// ------------------------------------------------------------------------------------------------
+// pack_params: flat state_dict-order parameters -> T-stream (forward) and N-stream (backward) blocks
+// ------------------------------------------------------------------------------------------------
+__global__ void gns_pack_params_kernel(const float* __restrict__ flat, float* __restrict__ pt, float* __restrict__ pn,
+                                       GnsFamilies fam, int K, int H) {
+  const int blk = blockIdx.x;            // (family, k)
+  const int f = blk / K, k = blk % K;
+  const int IN = fam.in[f], OUT = fam.out[f], OUTP = OUT + (OUT & 1), INP = IN + (IN & 1);
+  const float* src = flat + fam.flat_off[f] + (int64_t)k * fam.flat_sz[f];
+  const int sW1 = 0, sb1 = IN * H, sW2 = sb1 + H, sb2 = sW2 + H * H, sW4 = sb2 + H, sb4 = sW4 + OUT * H;
+  float* t = pt + fam.t_off[f] + (int64_t)k * fam.t_sz[f];
+  const int ob1 = IN * H, oW2 = ob1 + H, ob2 = oW2 + H * H, oW4 = ob2 + H, ob4 = oW4 + H * OUTP, tt = ob4 + OUTP;
+  for (int e = threadIdx.x; e < (int)fam.t_sz[f]; e += blockDim.x) {
+    float v = 0.f;
+    if (e < ob1) { int i = e / H, j = e % H; v = src[sW1 + j * IN + i]; }
+    else if (e < oW2) v = src[sb1 + (e - ob1)];
+    else if (e < ob2) { int q = e - oW2, i = q / H, j = q % H; v = src[sW2 + j * H + i]; }
+    else if (e < oW4) v = src[sb2 + (e - ob2)];
+    else if (e < ob4) { int q = e - oW4, i = q / OUTP, j = q % OUTP; v = j < OUT ? src[sW4 + j * H + i] : 0.f; }
+    else if (e < tt) { int j = e - ob4; v = j < OUT ? src[sb4 + j] : 0.f; }
+    t[e] = v;
+  }
+  float* n = pn + fam.n_off[f] + (int64_t)k * fam.n_sz[f];
+  const int nW2 = OUTP * H, nW1 = nW2 + H * H, nt = nW1 + H * INP;
+  for (int e = threadIdx.x; e < (int)fam.n_sz[f]; e += blockDim.x) {
+    float v = 0.f;
+    if (e < nW2) { int j = e / H, i = e % H; v = j < OUT ? src[sW4 + j * H + i] : 0.f; }
+    else if (e < nW1) { int q = e - nW2; v = src[sW2 + q]; }
+    else if (e < nt) { int q = e - nW1, j = q / INP, i = q % INP; v = i < IN ? src[sW1 + j * IN + i] : 0.f; }
+    n[e] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pack_inputs: reference layout [Bt,N,6] / [Bt,E,7] / [Bt,Gn,7] -> float4 rows [group][row][lane]
+// and the batch-invariant pieces of GNS.forward's prologue (main.py:144-152) and of the physics
+// (y = 1/sqrt(r^2+x^2), main.py:38,87; the bus-id-as-line-index gathers of y, tau, shift, b).
+// ------------------------------------------------------------------------------------------------
+__global__ void gns_pack_inputs_kernel(const int* __restrict__ topo, const float* __restrict__ buses,
+                                       const float* __restrict__ lines, const float* __restrict__ gens,
+                                       float* __restrict__ out, int N, int E, int Gn, long long Bt, long long rows) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long long g = blockIdx.y;
+  if (row >= rows) return;
+  long long b = g * GNS_LANES + lane;
+  if (b >= Bt) b = Bt - 1;               // dead lanes replay the last grid; their results are never stored
+  const float* bu = buses + b * (long long)N * 6;
+  const float* li = lines + b * (long long)E * 7;
+  const float* ge = gens + b * (long long)Gn * 7;
+  f4 o = {0.f, 0.f, 0.f, 0.f};
+  auto yline = [&](int l) {              // main.py:38: 1 / sqrt(r^2 + x^2), each op rounded like torch does
+    float r = li[l * 7 + 2], x = li[l * 7 + 3];
+    return __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(__fmul_rn(r, r), __fmul_rn(x, x))));
+  };
+  if (row < 3LL * N) {
+    const int n = (int)(row / 3), which = (int)(row % 3);
+    const float Pd = bu[n * 6 + 2], Qd = bu[n * 6 + 3], Gs = bu[n * 6 + 4], Bs = bu[n * 6 + 5];
+    if (which == 0) {
+      o = f4{Pd, Qd, Gs, Bs};
+    } else {
+      float pmin = 0.f, pset = 0.f, pmax = 0.f, vg = 0.f, pg = 0.f, qg = 0.f;
+      const int g0 = topo[topo[TH_GEN_PTR] + n], g1 = topo[topo[TH_GEN_PTR] + n + 1];
+      for (int q = g0; q < g1; ++q) {
+        const float* r = ge + topo[topo[TH_GEN_IDX] + q] * 7;     // (bus_i,Pmax,Pmin,Pg_set,vg,qg,Pg) utils.py:9
+        pmax += r[1]; pmin += r[2]; pset += r[3]; vg += r[4]; qg += r[5]; pg += r[6];
+      }
+      const float v0 = (vg == 0.f) ? 1.f : vg;                    // main.py:146-147
+      if (which == 1) o = f4{pmin, pset, pmax, v0};
+      else o = f4{__fsub_rn(__fsub_rn(pg, Pd), __fmul_rn(Gs, __fmul_rn(v0, v0))),     // main.py:150
+                  __fadd_rn(__fsub_rn(qg, Qd), __fmul_rn(Bs, __fmul_rn(v0, v0))), 0.f, 0.f};  // main.py:152
+    }
+  } else if (row < 3LL * N + 3LL * E) {
+    const long long r = row - 3LL * N;
+    const int p = (int)(r / 3), which = (int)(r % 3);
+    const int e = topo[topo[TH_IN_EID] + p], s = topo[topo[TH_IN_SRC] + p];
+    if (which == 0) o = f4{li[e * 7 + 2], li[e * 7 + 3], li[e * 7 + 4], li[e * 7 + 5]};
+    else if (which == 1) o = f4{li[e * 7 + 6], yline(s), li[s * 7 + 5], li[s * 7 + 6]};
+    else o = f4{li[s * 7 + 4], 0.f, 0.f, 0.f};
+  } else if (row < 3LL * N + 4LL * E) {
+    const int q = (int)(row - 3LL * N - 3LL * E);
+    const int t = topo[topo[TH_OUT_DST] + q];
+    o = f4{yline(t), li[t * 7 + 5], li[t * 7 + 6], li[t * 7 + 4]};
+  } else {
+    float sPd = 0.f, sset = 0.f, smin = 0.f, smax = 0.f;
+    for (int n = 0; n < N; ++n) sPd += bu[n * 6 + 2];
+    for (int q = 0; q < Gn; ++q) { smax += ge[q * 7 + 1]; smin += ge[q * 7 + 2]; sset += ge[q * 7 + 3]; }
+    o = f4{sPd, sset, smin, smax};
+  }
+  *row_ptr(out, g * rows + row, lane) = o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The fused forward kernel.
+// ------------------------------------------------------------------------------------------------
+template <int D, int H, bool MULTI>
+__global__ void __launch_bounds__(GNS_FWD_THREADS) gns_forward_kernel(GnsFwdArgs A) {
+  using C = GnsDims<D, H, MULTI>;
+  constexpr int MQ = C::MQ, RB = C::RB;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwaves = blockDim.x >> 6;
+  const long long g = blockIdx.x;
+  const int N = A.N, E = A.E, K = A.K;
+  cip topo = (cip)A.topo;
+  cfp PT = (cfp)A.pt;
+  const cip in_ptr = topo + topo[TH_IN_PTR], in_src = topo + topo[TH_IN_SRC], in_a = topo + topo[TH_IN_A],
+            in_b = topo + topo[TH_IN_B], out_ptr = topo + topo[TH_OUT_PTR], out_dst = topo + topo[TH_OUT_DST],
+            out_c = topo + topo[TH_OUT_C], out_d = topo + topo[TH_OUT_D], is_gen = topo + topo[TH_IS_GEN],
+            part = topo + topo[TH_PART] + A.part_idx * (GNS_MAXW + 1);
+  const int n0 = part[wave], n1 = part[wave + 1];
+  const long long R = gns_in_rows(N, E);
+  const float* IN = A.in;
+  const long long in_base = g * R;
+  const long long row_ein = in_base + 3LL * N, row_eout = row_ein + 3LL * E, row_grid = row_eout + E;
+  const long long b = g * GNS_LANES + lane;
+  const bool live = b < A.Bt;
+
+  __shared__ float red[2][GNS_MAXW][GNS_LANES][2];
+
+  auto state_row = [&](int slot, int n) { return (((long long)slot * A.G + g) * N + n) * RB; };
+
+  // ---- prologue (main.py:141-152): m = 0, theta = 0, v = vg or 1, delta_p/q from the set points
+  for (int n = n0; n < n1; ++n) {
+    const f4 b1 = *row_ptr(IN, in_base + 3LL * n + 1, lane), b2 = *row_ptr(IN, in_base + 3LL * n + 2, lane);
+    const long long r0 = state_row(0, n);
+    *row_ptr(A.state, r0, lane) = f4{b1.w, 0.f, b2.x, b2.y};
+#pragma unroll
+    for (int q = 0; q < MQ; ++q) *row_ptr(A.state, r0 + 1 + q, lane) = f4{0.f, 0.f, 0.f, 0.f};
+  }
+  const f4 gsum = *row_ptr(IN, row_grid, lane);     // (sumPd, sumPset, sumPmin, sumPmax)
+  float tot_part = 0.f, last_part = 0.f;
+  const float invN = 1.0f / (float)N;
+
+  for (int k = 0; k < K; ++k) {
+    const int rs = A.save ? k : 0, ws = A.save ? k + 1 : 0;
+    const long long koff = (long long)k;
+    // ================= phase U: latent / v / theta update, one bus at a time (main.py:155-188) ========
+    for (int n = n0; n < n1; ++n) {
+      const long long rr = state_row(rs, n), wr = state_row(ws, n);
+      const f4 s0 = *row_ptr(A.state, rr, lane);
+      float m[D];
+      load_vec<D>(A.state, rr + 1, lane, m);
+      f2 S[C::NPHI][C::PHI_OUTP / 2];
+#pragma unroll
+      for (int f = 0; f < C::NPHI; ++f)
+#pragma unroll
+        for (int j = 0; j < C::PHI_OUTP / 2; ++j) S[f][j] = f2{0.f, 0.f};
+      const int p0 = in_ptr[n], p1 = in_ptr[n + 1];
+      for (int p = p0; p < p1; ++p) {                  // messages of the lines ending at n (main.py:155-163)
+        const f4 e0 = *row_ptr(IN, row_ein + 3LL * p, lane), e1 = *row_ptr(IN, row_ein + 3LL * p + 1, lane);
+        float x[C::PHI_IN];
+#pragma unroll
+        for (int i = 0; i < D; ++i) x[i] = m[i];
+        x[D] = e0.x; x[D + 1] = e0.y; x[D + 2] = e0.z; x[D + 3] = e0.w; x[D + 4] = e1.x;
+        static_for<0, C::NPHI>([&](auto f_) {
+          constexpr int f = decltype(f_)::value;
+          f2 a1[H / 2], a2[H / 2], y[C::PHI_OUTP / 2];
+          mlp_fwd<C::PHI_IN, H, C::PHI_OUTP>(PT + A.t_off[f] + koff * A.t_sz[f], x, a1, a2, y);
+#pragma unroll
+          for (int j = 0; j < C::PHI_OUTP / 2; ++j) S[f][j] += y[j];
+        });
+      }
+      float upd_theta, upd_v;
+      f2 upd_m[D / 2];
+      static_for<0, 3>([&](auto l_) {                  // l: 0 = L_theta, 1 = L_v, 2 = L_m   (main.py:173-180)
+        constexpr int l = decltype(l_)::value;
+        constexpr int fphi = MULTI ? (l == 0 ? 1 : (l == 1 ? 0 : 2)) : 0;   // phi_theta, phi_v, phi_m
+        float x[C::L_IN];
+        x[0] = s0.x; x[1] = s0.y; x[2] = s0.z; x[3] = s0.w;
+#pragma unroll
+        for (int i = 0; i < D; ++i) x[4 + i] = m[i];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+          if constexpr (MULTI) x[4 + D + i] = (i & 1) ? S[fphi][i / 2].y : S[fphi][i / 2].x;
+          else x[4 + D + i] = (i == 0) ? S[0][0].x : 0.f;           // [E,1] scattered into column 0 (main.py:170)
+        }
+        f2 a1[H / 2], a2[H / 2];
+        if constexpr (l < 2) {
+          f2 y[1];
+          mlp_fwd<C::L_IN, H, 2>(PT + A.t_off[C::NPHI + l] + koff * A.t_sz[C::NPHI + l], x, a1, a2, y);
+          if constexpr (l == 0) upd_theta = y[0].x; else upd_v = y[0].x;
+        } else {
+          mlp_fwd<C::L_IN, H, D>(PT + A.t_off[C::NPHI + 2] + koff * A.t_sz[C::NPHI + 2], x, a1, a2, upd_m);
+        }
+      });
+      const float th_new = s0.y + upd_theta;                          // main.py:182
+      const float v_new = is_gen[n] ? s0.x : s0.x + upd_v;           // main.py:184-186
+      *row_ptr(A.state, wr, lane) = f4{v_new, th_new, 0.f, 0.f};
+      float m_new[D];
+      static_for<0, D>([&](auto i_) { constexpr int i = decltype(i_)::value; m_new[i] = m[i] + lane_of<i>(upd_m); });   // main.py:188
+      store_vec<D>(A.state, wr + 1, lane, m_new);
+    }
+    __syncthreads();   // every bus of the 64 grids now has v_{k+1}, theta_{k+1}
+
+    // ================= phase P: line physics (main.py:34-104), bus-centric, no scatter ================
+    float joule = 0.f, v2gs = 0.f;
+    for (int n = n0; n < n1; ++n) {
+      const long long wr = state_row(ws, n);
+      const f4 sn = *row_ptr(A.state, wr, lane);
+      const float vn = sn.x, thn = sn.y;
+      const f4 b0 = *row_ptr(IN, in_base + 3LL * n, lane);            // Pd,Qd,Gs,Bs
+      float sum_pf = 0.f, sum_qf = 0.f, sum_pt = 0.f, sum_qt = 0.f, agg = 0.f;
+      const int p0 = in_ptr[n], p1 = in_ptr[n + 1];
+      for (int p = p0; p < p1; ++p) {                                 // lines with dst == n ("from" messages)
+        const int s = in_src[p], ia = in_a[p], ib = in_b[p];
+        const f4 e1 = *row_ptr(IN, row_ein + 3LL * p + 1, lane), e2 = *row_ptr(IN, row_ein + 3LL * p + 2, lane);
+        const f4 ss = *row_ptr(A.state, state_row(ws, s), lane);
+        const float tha = row_ptr(A.state, state_row(ws, ia), lane)->y, thb = row_ptr(A.state, state_row(ws, ib), lane)->y;
+        const float vs = ss.x, ths = ss.y, vt = vn, tht = thn;
+        const float ys = e1.y, taus = e1.z, shs = e1.w, bs = e2.x;
+        const float dl = tha - thb;                                   // delta_ij[src]  (bus id used as line index)
+        const float angA = ths - tht - dl - shs, angB = tht - ths - dl + shs;
+        float sA, cA, sD, cD;
+        sincosf(angA, &sA, &cA);
+        sincosf(dl, &sD, &cD);
+        const float sB = sinf(angB);
+        const float base = vs * vt * ys / taus;
+        const float msg = fabsf(base * (sA + sB) + (vs / (taus * taus)) * ys * sD + (vt * vt) * ys * sD);   // main.py:41
+        agg += msg;
+        const float vst = vs / taus, vst2 = vst * vst;
+        sum_pf += base * sA + vst2 * ys * sD;                          // main.py:91
+        sum_qf += -base * cA + vst2 * (ys * cD - bs / 2.f);            // main.py:68-69 == :98
+      }
+      const int q0 = out_ptr[n], q1 = out_ptr[n + 1];
+      for (int q = q0; q < q1; ++q) {                                 // lines with src == n ("to" messages)
+        const int t = out_dst[q], ic = out_c[q], id = out_d[q];
+        const f4 o0 = *row_ptr(IN, row_eout + q, lane);               // y_t, tau_t, sh_t, b_t
+        const f4 st = *row_ptr(A.state, state_row(ws, t), lane);
+        const float thc = row_ptr(A.state, state_row(ws, ic), lane)->y, thd = row_ptr(A.state, state_row(ws, id), lane)->y;
+        const float vs = vn, ths = thn, vt = st.x, tht = st.y;
+        const float dl = thd - thc;                                   // delta_ji[dst]
+        const float angC = tht - ths - dl - o0.z;
+        float sC, cC;
+        sincosf(angC, &sC, &cC);
+        const float sD = sinf(dl);
+        const float base = vt * vs * o0.x / o0.y;
+        sum_pt += base * sC + (vt * vt) * o0.x * sD;                   // main.py:92
+        sum_qt += -base * cC + (vt * vt) * (o0.x * sD - o0.w / 2.f);   // main.py:70-72 == :99
+      }
+      joule += agg;
+      const float v2 = vn * vn;
+      v2gs += v2 * b0.z;
+      const float dp_pre = ((0.f - b0.x) - b0.z * v2) + sum_pf + sum_pt;     // main.py:82,96 without the generator term
+      const float qg_new = ((b0.y - b0.w * v2) - sum_qf) - sum_qt;           // main.py:64,76
+      const float dq = ((qg_new - b0.y) + b0.w * v2) + sum_qf + sum_qt;      // main.py:83,103 (cancels to rounding noise)
+      *row_ptr(A.state, wr, lane) = f4{vn, thn, dp_pre, dq};
+    }
+    red[k & 1][wave][lane][0] = joule;
+    red[k & 1][wave][lane][1] = v2gs;
+    __syncthreads();
+    float jsum = 0.f, vsum = 0.f;
+    for (int w = 0; w < nwaves; ++w) { jsum += red[k & 1][w][lane][0]; vsum += red[k & 1][w][lane][1]; }
+    // global active compensation (main.py:45-57)
+    const float p_global = (gsum.x + vsum) + jsum;
+    float lam;
+    const bool low1 = p_global < gsum.y;
+    if (low1) lam = (p_global - gsum.z) / (2.f * (gsum.y - gsum.z));
+    else lam = (p_global - 2.f * gsum.y + gsum.w) / (2.f * (gsum.w - gsum.y));
+    const bool low2 = lam < 0.5f;
+    if (A.save && wave == 0)
+      reinterpret_cast<f2*>(A.lam)[((long long)k * A.G + g) * GNS_LANES + lane] = f2{lam, (low1 ? 1.f : 0.f) + (low2 ? 2.f : 0.f)};
+    float sq = 0.f;
+    for (int n = n0; n < n1; ++n) {
+      const long long wr = state_row(ws, n);
+      const f4 b1 = *row_ptr(IN, in_base + 3LL * n + 1, lane);         // Pmin,Pset,Pmax,v0 summed per bus
+      f4 sn = *row_ptr(A.state, wr, lane);
+      const float pg = low2 ? b1.x + 2.f * (b1.y - b1.x) * lam : 2.f * b1.y - b1.z + 2.f * (b1.z - b1.y) * lam;   // main.py:53-57
+      sn.z = pg + sn.z;                                               // main.py:81-82,96
+      *row_ptr(A.state, wr, lane) = sn;
+      sq += sn.z * sn.z + sn.w * sn.w;
+    }
+    tot_part += A.gw[k] * (sq * invN);           // main.py:198
+    last_part = sq * invN;                                            // main.py:199
+  }
+
+  // ---- epilogue: outputs (main.py:199-202) ---------------------------------------------------------
+  const int fs = A.save ? K : 0;
+  if (live) {
+    for (int n = n0; n < n1; ++n) {
+      const f4 sn = *row_ptr(A.state, state_row(fs, n), lane);
+      A.v_out[b * N + n] = (sn.x < 0.f) ? 0.f : sn.x;                 // main.py:201
+      A.theta_out[b * N + n] = sn.y;
+    }
+  }
+  __syncthreads();
+  red[0][wave][lane][0] = tot_part;
+  red[0][wave][lane][1] = last_part;
+  __syncthreads();
+  if (wave == 0 && live) {
+    float t = 0.f, l = 0.f;
+    for (int w = 0; w < nwaves; ++w) { t += red[0][w][lane][0]; l += red[0][w][lane][1]; }
+    A.total_out[b] = t;
+    A.last_out[b] = l;
+  }
+}
+
+template <int D, int H, bool MULTI>
+static int launch_forward_t(const GnsFwdArgs& A, int threads, hipStream_t st) {
+  hipLaunchKernelGGL((gns_forward_kernel<D, H, MULTI>), dim3((unsigned)A.G), dim3(threads), 0, st, A);
+  return hipGetLastError() == hipSuccess ? GNS_OK : GNS_ELAUNCH;
+}
+
+int gns_launch_forward(int d, int h, int multi, const GnsFwdArgs& A, int threads, hipStream_t st) {
+#define GNS_CASE(DD, HH)                                                                     \
+  if (d == DD && h == HH) return multi ? launch_forward_t<DD, HH, true>(A, threads, st)      \
+                                       : launch_forward_t<DD, HH, false>(A, threads, st);
+  GNS_FOR_EACH_DIMS(GNS_CASE)
+#undef GNS_CASE
+  return GNS_EUNSUPPORTED;
+}
+
+int gns_launch_pack_params(const float* flat, float* pt, float* pn, const GnsFamilies& fam, int K, int H, hipStream_t st) {
+  hipLaunchKernelGGL(gns_pack_params_kernel, dim3(fam.nfam * K), dim3(256), 0, st, flat, pt, pn, fam, K, H);
+  return hipGetLastError() == hipSuccess ? GNS_OK : GNS_ELAUNCH;
+}
+
+int gns_launch_pack_inputs(const int* topo, const float* buses, const float* lines, const float* gens, float* out, int N,
+                           int E, int Gn, long long Bt, long long groups, hipStream_t st) {
+  const long long rows = gns_in_rows(N, E);
+  dim3 grid((unsigned)((rows + 3) / 4), (unsigned)groups);
+  hipLaunchKernelGGL(gns_pack_inputs_kernel, grid, dim3(256), 0, st, topo, buses, lines, gens, out, N, E, Gn, Bt, rows);
+  return hipGetLastError() == hipSuccess ? GNS_OK : GNS_ELAUNCH;
+}

@@ -1,0 +1,41 @@
+// Kernel argument blocks and launch entry points shared between the .hip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/gns_hip.h"
+#include "gns_common.h"
+
+#define GNS_FWD_THREADS 512      // 8 waves split the buses of 64 grids
+#define GNS_BWD_THREADS 512
+#define GNS_MAX_K 64
+
+// (latent_dim, hidden_dim) pairs with compiled kernels
+#define GNS_FOR_EACH_DIMS(X) X(20, 10) X(10, 10)
+
+template <int D, int H, bool MULTI>
+struct GnsDims {
+  static constexpr int NPHI = MULTI ? 3 : 1;
+  static constexpr int PHI_IN = D + 5;                 // [m(dst) | r x b tau shift]        main.py:155
+  static constexpr int PHI_OUT = MULTI ? D : 1;        // main.py:126-130
+  static constexpr int PHI_OUTP = PHI_OUT + (PHI_OUT & 1);
+  static constexpr int L_IN = 4 + 2 * D;               // [v theta dp dq | m | phi_sum]      main.py:165-171
+  static constexpr int MQ = (D + 3) / 4;               // float4 rows of the latent vector
+  static constexpr int RB = 1 + MQ;                    // state rows per bus: (v,theta,dp,dq) + m
+};
+
+struct GnsFwdArgs {
+  const int* topo;
+  const float* pt;        // T-stream parameters
+  const float* in;        // packed inputs
+  float* state;           // [slots][G][N][RB][64] float4
+  float* lam;             // [K][G][64] float2 (lambda, branch bits) when save != 0
+  float* v_out; float* theta_out; float* total_out; float* last_out;
+  long long t_off[6], t_sz[6];
+  float gw[GNS_MAX_K];    // gamma^(K-k) rounded to fp32 from a double, like the reference's python float
+  long long Bt, G;
+  int N, E, K, save, zero, part_idx;
+};
+
+int gns_launch_forward(int d, int h, int multi, const GnsFwdArgs& A, int threads, hipStream_t st);
+int gns_launch_pack_params(const float* flat, float* pt, float* pn, const GnsFamilies& fam, int K, int H, hipStream_t st);
+int gns_launch_pack_inputs(const int* topo, const float* buses, const float* lines, const float* gens, float* out, int N,
+                           int E, int Gn, long long Bt, long long groups, hipStream_t st);

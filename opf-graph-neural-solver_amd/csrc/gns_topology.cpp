@@ -1,0 +1,134 @@
+// Host-side topology preparation: everything the reference recomputes per call from the id columns
+// (GNS/main.py:35-36,85-86,144,153,184-185) is built once per case into one relocatable int32 blob.
+#include "../../include/gns_hip.h"
+#include "gns_common.h"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+namespace {
+
+struct Blob {
+  std::vector<int32_t> w;
+  explicit Blob() : w(TH_HDR_WORDS, 0) {}
+  void put(int slot, const std::vector<int32_t>& a) { w[slot] = (int32_t)w.size(); w.insert(w.end(), a.begin(), a.end()); }
+};
+
+// contiguous ranges over `cost`, balanced for `waves` parts, written to out[0..GNS_MAXW]
+void balanced_ranges(const std::vector<double>& cost, int waves, int32_t* out) {
+  const int n = (int)cost.size();
+  double total = std::accumulate(cost.begin(), cost.end(), 0.0);
+  out[0] = 0;
+  double run = 0; int w = 1;
+  for (int i = 0; i < n && w < waves; ++i) {
+    run += cost[i];
+    // cut after element i once this part holds its share; leave at least one element for each remaining part when possible
+    while (w < waves && run >= total * w / waves - 1e-9) { out[w] = std::min(i + 1, n); ++w; }
+  }
+  for (; w <= GNS_MAXW; ++w) out[w] = n;
+  for (w = 1; w <= GNS_MAXW; ++w) out[w] = std::max(out[w], out[w - 1]);
+  for (w = waves; w <= GNS_MAXW; ++w) out[w] = n;
+}
+
+int build(int N, int E, int Gn, const int32_t* src, const int32_t* dst, const int32_t* gen_bus, std::vector<int32_t>& out) {
+  if (N <= 0 || E <= 0 || Gn < 0 || !src || !dst || (Gn > 0 && !gen_bus)) return GNS_EINVAL;
+  for (int e = 0; e < E; ++e) {
+    if (src[e] < 0 || src[e] >= N || dst[e] < 0 || dst[e] >= N) return GNS_ETOPOLOGY;
+    // the reference gathers per-LINE arrays with BUS ids (y_ij[src], delta_ij[src], ...): ids must be line indices
+    if (src[e] >= E || dst[e] >= E) return GNS_ETOPOLOGY;
+  }
+  for (int g = 0; g < Gn; ++g) if (gen_bus[g] < 0 || gen_bus[g] >= N) return GNS_ETOPOLOGY;
+
+  Blob b;
+  b.w[TH_MAGIC] = GNS_TOPO_MAGIC; b.w[TH_N] = N; b.w[TH_E] = E; b.w[TH_GN] = Gn;
+
+  // stable counting sorts by destination and by source
+  std::vector<int32_t> in_ptr(N + 1, 0), out_ptr(N + 1, 0), in_eid(E), out_eid(E);
+  for (int e = 0; e < E; ++e) { ++in_ptr[dst[e] + 1]; ++out_ptr[src[e] + 1]; }
+  for (int n = 0; n < N; ++n) { in_ptr[n + 1] += in_ptr[n]; out_ptr[n + 1] += out_ptr[n]; }
+  {
+    std::vector<int32_t> ci(in_ptr.begin(), in_ptr.end() - 1), co(out_ptr.begin(), out_ptr.end() - 1);
+    for (int e = 0; e < E; ++e) { in_eid[ci[dst[e]]++] = e; out_eid[co[src[e]]++] = e; }
+  }
+  std::vector<int32_t> in_src(E), in_a(E), in_b(E), out_dst(E), out_c(E), out_d(E), p2q(E), q2p(E), pos_out(E);
+  for (int q = 0; q < E; ++q) pos_out[out_eid[q]] = q;
+  for (int p = 0; p < E; ++p) {
+    const int e = in_eid[p], s = src[e];
+    in_src[p] = s; in_a[p] = src[s]; in_b[p] = dst[s];          // line NUMBER s
+    p2q[p] = pos_out[e]; q2p[pos_out[e]] = p;
+  }
+  for (int q = 0; q < E; ++q) {
+    const int e = out_eid[q], t = dst[e];
+    out_dst[q] = t; out_c[q] = src[t]; out_d[q] = dst[t];        // line NUMBER t
+  }
+  std::vector<int32_t> is_gen(N, 0), gen_ptr(N + 1, 0), gen_idx(std::max(Gn, 1), 0);
+  for (int g = 0; g < Gn; ++g) { is_gen[gen_bus[g]] = 1; ++gen_ptr[gen_bus[g] + 1]; }
+  for (int n = 0; n < N; ++n) gen_ptr[n + 1] += gen_ptr[n];
+  {
+    std::vector<int32_t> c(gen_ptr.begin(), gen_ptr.end() - 1);
+    for (int g = 0; g < Gn; ++g) gen_idx[c[gen_bus[g]]++] = g;
+  }
+  // incidence lists of the two delta adjoints: edge p touches theta[a],theta[b] (dbar) and theta[d],theta[c] (dbar')
+  std::vector<int32_t> incd_ptr(N + 1, 0), incd(4 * (size_t)E);
+  {
+    std::vector<std::vector<int32_t>> lists(N);
+    for (int p = 0; p < E; ++p) {
+      const int q = p2q[p];
+      lists[in_a[p]].push_back(p * 4 + 0);
+      lists[in_b[p]].push_back(p * 4 + 1);
+      lists[out_d[q]].push_back(p * 4 + 2);
+      lists[out_c[q]].push_back(p * 4 + 3);
+    }
+    size_t o = 0;
+    for (int n = 0; n < N; ++n) { incd_ptr[n] = (int32_t)o; for (int32_t v : lists[n]) incd[o++] = v; }
+    incd_ptr[N] = (int32_t)o;
+  }
+  // bus partitions: cost ~ packed-FMA instructions of the update phase + the physics of incident lines
+  std::vector<double> cost(N), ecost(E, 1.0);
+  for (int n = 0; n < N; ++n) {
+    const int din = in_ptr[n + 1] - in_ptr[n], dout = out_ptr[n + 1] - out_ptr[n];
+    cost[n] = 950.0 + 1075.0 * din + 150.0 * dout + 40.0 * (incd_ptr[n + 1] - incd_ptr[n]) * 0.25;
+  }
+  std::vector<int32_t> part(GNS_NPART * (GNS_MAXW + 1)), epart(GNS_NPART * (GNS_MAXW + 1));
+  const int wopts[GNS_NPART] = {1, 2, 4, 8, 16};
+  for (int i = 0; i < GNS_NPART; ++i) {
+    balanced_ranges(cost, wopts[i], &part[i * (GNS_MAXW + 1)]);
+    balanced_ranges(ecost, wopts[i], &epart[i * (GNS_MAXW + 1)]);
+  }
+
+  b.put(TH_IN_PTR, in_ptr); b.put(TH_IN_EID, in_eid); b.put(TH_IN_SRC, in_src); b.put(TH_IN_A, in_a); b.put(TH_IN_B, in_b);
+  b.put(TH_OUT_PTR, out_ptr); b.put(TH_OUT_EID, out_eid); b.put(TH_OUT_DST, out_dst); b.put(TH_OUT_C, out_c); b.put(TH_OUT_D, out_d);
+  b.put(TH_IS_GEN, is_gen); b.put(TH_GEN_PTR, gen_ptr); b.put(TH_GEN_IDX, gen_idx);
+  b.put(TH_PART, part); b.put(TH_P2Q, p2q); b.put(TH_Q2P, q2p); b.put(TH_EPART, epart);
+  b.put(TH_INCD_PTR, incd_ptr); b.put(TH_INCD, incd);
+  b.w[TH_TOTAL] = (int32_t)b.w.size();
+  out.swap(b.w);
+  return GNS_OK;
+}
+
+size_t blob_words(int N, int E, int Gn) {
+  return TH_HDR_WORDS + 2 * (size_t)(N + 1) + 12 * (size_t)E + (size_t)N + (size_t)(N + 1) + (size_t)std::max(Gn, 1)
+         + 2 * (size_t)GNS_NPART * (GNS_MAXW + 1) + (size_t)(N + 1) + 4 * (size_t)E;
+}
+
+}  // namespace
+
+extern "C" int gns_topology_bytes(int32_t n_bus, int32_t n_line, int32_t n_gen, size_t* bytes) {
+  if (!bytes || n_bus <= 0 || n_line <= 0 || n_gen < 0) return GNS_EINVAL;
+  *bytes = blob_words(n_bus, n_line, n_gen) * sizeof(int32_t);
+  return GNS_OK;
+}
+
+extern "C" int gns_prepare_topology(int32_t n_bus, int32_t n_line, int32_t n_gen, const int32_t* src, const int32_t* dst,
+                                    const int32_t* gen_bus, void* topo_host_out, size_t topo_bytes) {
+  if (!topo_host_out) return GNS_EINVAL;
+  std::vector<int32_t> w;
+  int rc = GNS_EINVAL;
+  try { rc = build(n_bus, n_line, n_gen, src, dst, gen_bus, w); } catch (...) { return GNS_EINVAL; }
+  if (rc != GNS_OK) return rc;
+  if (w.size() * sizeof(int32_t) > topo_bytes) return GNS_ESIZE;
+  std::memcpy(topo_host_out, w.data(), w.size() * sizeof(int32_t));
+  return GNS_OK;
+}

@@ -1,0 +1,277 @@
+"""``GNS`` nn.Module: the reference's operator interface (GNS/main.py:107-202) over the HIP hot path.
+
+Host side only - parameter bookkeeping, validation, topology caching, autograd glue.  All arithmetic of
+the K-step loop happens in ``libgns_hip.so``.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ._lib import GNS_ERRORS, GnsConfig, load_library
+
+
+class GNSError(RuntimeError):
+    pass
+
+
+def get_BLG():
+    """Column maps of the bus / line / generator tensors (GNS/utils.py:4-13)."""
+    B = {'bus_i': 0, 'type': 1, 'Pd': 2, 'Qd': 3, 'Gs': 4, 'Bs': 5}
+    L = {'f_bus': 0, 't_bus': 1, 'r': 2, 'x': 3, 'b': 4, 'tau': 5, 'theta': 6}
+    G = {'bus_i': 0, 'Pmax': 1, 'Pmin': 2, 'Pg_set': 3, 'vg': 4, 'qg': 5, 'Pg': 6}
+    return B, L, G
+
+
+_B0, _L0, _G0 = get_BLG()
+
+
+class LearningBlock(nn.Module):
+    """Parameter container with the reference's layer names ``linear1, linear2, linear4`` (GNS/main.py:17-31).
+    ``forward`` is plain torch and exists for callers that use a block on its own; the fused GNS path reads the
+    parameters directly."""
+
+    def __init__(self, dim_in, hidden_dim, dim_out):
+        super().__init__()
+        self.linear1 = nn.Linear(dim_in, hidden_dim)
+        self.linear2 = nn.Linear(hidden_dim, hidden_dim)
+        self.linear4 = nn.Linear(hidden_dim, dim_out)
+        self.lrelu = nn.LeakyReLU()
+
+    def forward(self, x):
+        return self.linear4(self.lrelu(self.linear2(self.lrelu(self.linear1(x)))))
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise GNSError(f'{what} failed: {GNS_ERRORS.get(rc, rc)}')
+
+
+class _Topology:
+    """Device-resident topology blob of one case + the id columns it was built from."""
+
+    def __init__(self, lib, src, dst, gen_bus, device):
+        n_line, n_gen = int(src.size), int(gen_bus.size)
+        self.src, self.dst, self.gen_bus = src, dst, gen_bus
+        self.n_line, self.n_gen = n_line, n_gen
+
+    @staticmethod
+    def build(lib, n_bus, src, dst, gen_bus, device):
+        t = _Topology(lib, src, dst, gen_bus, device)
+        t.n_bus = n_bus
+        nbytes = ctypes.c_size_t()
+        _check(lib.gns_topology_bytes(n_bus, t.n_line, t.n_gen, ctypes.byref(nbytes)), 'gns_topology_bytes')
+        host = np.zeros(nbytes.value // 4, dtype=np.int32)
+        s32, d32 = np.ascontiguousarray(src, dtype=np.int32), np.ascontiguousarray(dst, dtype=np.int32)
+        g32 = np.ascontiguousarray(gen_bus if gen_bus.size else np.zeros(1), dtype=np.int32)
+        rc = lib.gns_prepare_topology(n_bus, t.n_line, t.n_gen, s32.ctypes.data, d32.ctypes.data, g32.ctypes.data,
+                                      host.ctypes.data, host.nbytes)
+        if rc == 3:
+            raise ValueError('invalid topology: bus ids must be 1..N and, because the reference gathers per-line '
+                             'arrays with bus ids (GNS/main.py:41), every connected bus id must also be <= E')
+        _check(rc, 'gns_prepare_topology')
+        t.blob = torch.from_numpy(host).to(device)
+        return t
+
+
+class _GNSFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, topo, buses, lines, gens, *params):
+        lib = load_library()
+        Bt, N = buses.shape[0], buses.shape[1]
+        cfg = mod._config(N, lines.shape[1], gens.shape[1])
+        dev = buses.device
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        fwd_b, bwd_b = ctypes.c_size_t(), ctypes.c_size_t()
+        _check(lib.gns_workspace_bytes(ctypes.byref(cfg), Bt, int(need_grad), ctypes.byref(fwd_b), ctypes.byref(bwd_b)),
+               'gns_workspace_bytes')
+        ws = torch.empty(fwd_b.value, dtype=torch.uint8, device=dev)
+        v = torch.empty((Bt, N), dtype=torch.float32, device=dev)
+        theta = torch.empty_like(v)
+        total = torch.empty(Bt, dtype=torch.float32, device=dev)
+        last = torch.empty_like(total)
+        flat = mod._flat
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _check(lib.gns_forward(ctypes.byref(cfg), topo.blob.data_ptr(), flat.data_ptr(), buses.data_ptr(), lines.data_ptr(),
+                               gens.data_ptr(), Bt, v.data_ptr(), theta.data_ptr(), total.data_ptr(), last.data_ptr(),
+                               ws.data_ptr(), ws.numel(), int(need_grad), stream), 'gns_forward')
+        if need_grad:
+            ctx.cfg, ctx.topo, ctx.ws, ctx.flat, ctx.Bt, ctx.bwd_bytes = cfg, topo, ws, flat, Bt, bwd_b.value
+            ctx.shapes = [p.shape for p in params]
+            ctx.flat_version = flat._version
+        return v, theta, total, last
+
+    @staticmethod
+    def backward(ctx, gv, gth, gtot, glast):
+        lib = load_library()
+        flat = ctx.flat
+        if flat._version != ctx.flat_version:
+            raise GNSError('parameters were modified in place between forward and backward')
+        dev = flat.device
+        grad = torch.zeros_like(flat)
+        bws = torch.empty(ctx.bwd_bytes, dtype=torch.uint8, device=dev)
+
+        def ptr(t):
+            return None if t is None else t.contiguous().data_ptr()
+
+        keep = [t.contiguous() if t is not None else None for t in (gtot, glast, gv, gth)]
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _check(lib.gns_backward(ctypes.byref(ctx.cfg), ctx.topo.blob.data_ptr(), flat.data_ptr(), ctx.Bt, ctx.ws.data_ptr(),
+                                ctx.ws.numel(), ptr(keep[0]), ptr(keep[1]), ptr(keep[2]), ptr(keep[3]), grad.data_ptr(),
+                                bws.data_ptr(), bws.numel(), stream), 'gns_backward')
+        out, off = [], 0
+        for shp in ctx.shapes:
+            n = int(np.prod(shp))
+            out.append(grad[off:off + n].view(shp))
+            off += n
+        return (None, None, None, None, None, *out)
+
+
+class GNS(nn.Module):
+    """Drop-in for the reference's ``GNS`` (GNS/main.py:107-202) with a batched extension.
+
+    ``forward(buses[N,6], lines[E,7], generators[Gn,7], B, L, G)`` returns ``(v[N], theta[N], total_loss[], last_loss[])``
+    like the reference.  Additionally 3-D inputs ``[Bt,N,6], [Bt,E,7], [Bt,Gn,7]`` (what ``utils.load_all_grids``
+    returns) give ``(v[Bt,N], theta[Bt,N], total_loss[Bt], last_loss[Bt])``; the topology columns must be identical
+    across the batch.  ``state_dict`` keys and shapes are the reference's.
+    """
+
+    def __init__(self, latent_dim=10, hidden_dim=10, K=30, gamma=0.9, multiple_phi=False):
+        super().__init__()
+        self.multiple_phis = multiple_phi                      # attribute name of the reference (main.py:111)
+        if self.multiple_phis:
+            self.phi_v = nn.ModuleDict()
+            self.phi_theta = nn.ModuleDict()
+            self.phi_m = nn.ModuleDict()
+        else:
+            self.phi = nn.ModuleDict()
+        self.L_theta = nn.ModuleDict()
+        self.L_v = nn.ModuleDict()
+        self.L_m = nn.ModuleDict()
+        for k in range(K):                                     # same construction order => same RNG stream as the reference
+            if self.multiple_phis:
+                self.phi_v[str(k)] = LearningBlock(5 + latent_dim, hidden_dim, latent_dim)
+                self.phi_theta[str(k)] = LearningBlock(5 + latent_dim, hidden_dim, latent_dim)
+                self.phi_m[str(k)] = LearningBlock(5 + latent_dim, hidden_dim, latent_dim)
+            else:
+                self.phi[str(k)] = LearningBlock(5 + latent_dim, hidden_dim, 1)
+            self.L_theta[str(k)] = LearningBlock(4 + 2 * latent_dim, hidden_dim, 1)
+            self.L_v[str(k)] = LearningBlock(4 + 2 * latent_dim, hidden_dim, 1)
+            self.L_m[str(k)] = LearningBlock(4 + 2 * latent_dim, hidden_dim, latent_dim)
+        self.latent_dim = latent_dim
+        self.hidden_dim = hidden_dim
+        self.gamma = gamma
+        self.K = K
+        # host-side state (not parameters / buffers: they must not appear in state_dict)
+        self.__dict__['_flat'] = None
+        self.__dict__['_topo_cache'] = {}
+        self.topology_check = 'always'    # 'always': compare id columns on every call; 'first': only when a case is first seen
+
+    # ---- flat parameter storage -------------------------------------------------------------------
+    def _config(self, n_bus, n_line, n_gen):
+        return GnsConfig(n_bus, n_line, n_gen, self.K, self.latent_dim, self.hidden_dim, int(self.multiple_phis),
+                         float(self.gamma))
+
+    def _ensure_flat(self):
+        """All parameters are views of ONE contiguous fp32 buffer in state_dict order: it is what the kernels read
+        and what a data-parallel all-reduce sends.  Re-established after .to()/.load_state_dict() replaced storages."""
+        params = list(self.parameters())
+        flat = self._flat
+        ok = flat is not None and flat.device == params[0].device
+        if ok:
+            off, base, esz = 0, flat.data_ptr(), 4
+            for p in params:
+                if p.dtype != torch.float32 or p.data_ptr() != base + off * esz or not p.is_contiguous():
+                    ok = False
+                    break
+                off += p.numel()
+        if not ok:
+            if any(p.dtype != torch.float32 for p in params):
+                raise GNSError('GNS parameters must be float32')
+            flat = torch.cat([p.detach().reshape(-1) for p in params]).contiguous()
+            off = 0
+            for p in params:
+                p.data = flat[off:off + p.numel()].view(p.shape)
+                off += p.numel()
+            self.__dict__['_flat'] = flat
+        return params
+
+    def flat_parameters(self):
+        """The flat fp32 parameter buffer (state_dict order); parameters are views into it."""
+        self._ensure_flat()
+        return self._flat
+
+    # ---- topology -----------------------------------------------------------------------------------
+    def _topology(self, lines3, gens3, n_bus):
+        dev = lines3.device
+        key = (n_bus, lines3.shape[1], gens3.shape[1], str(dev))
+        ids_l = lines3[0, :, 0:2]
+        ids_g = gens3[0, :, 0]
+        ent = self._topo_cache.get(key)
+        if ent is not None and self.topology_check != 'always':
+            return ent[0]
+        if ent is not None:
+            same = bool((torch.equal(ids_l, ent[1]) and torch.equal(ids_g, ent[2])
+                         and bool((lines3[:, :, 0:2] == ids_l).all()) and bool((gens3[:, :, 0] == ids_g).all())))
+            if same:
+                return ent[0]
+        if not (bool((lines3[:, :, 0:2] == ids_l).all()) and bool((gens3[:, :, 0] == ids_g).all())):
+            raise ValueError('f_bus / t_bus / generator bus columns differ across the batch: the fused path needs one '
+                             'topology per call (group grids by topology on the host)')
+        l_np, g_np = ids_l.detach().cpu().numpy().astype(np.float64), ids_g.detach().cpu().numpy().astype(np.float64)
+        if not (np.all(l_np == np.round(l_np)) and np.all(g_np == np.round(g_np))):
+            raise ValueError('bus id columns must hold integers')
+        src, dst, gb = l_np[:, 0].astype(np.int64) - 1, l_np[:, 1].astype(np.int64) - 1, g_np.astype(np.int64) - 1
+        if src.min(initial=0) < 0 or dst.min(initial=0) < 0 or max(src.max(initial=0), dst.max(initial=0)) >= n_bus \
+                or (gb.size and (gb.min() < 0 or gb.max() >= n_bus)):
+            raise ValueError(f'bus ids must lie in 1..{n_bus}')
+        topo = _Topology.build(load_library(), n_bus, src, dst, gb, dev)
+        self._topo_cache[key] = (topo, ids_l.clone(), ids_g.clone())
+        return topo
+
+    # ---- forward --------------------------------------------------------------------------------------
+    @staticmethod
+    def _remap(t, cols, default):
+        if cols is None or dict(cols) == default:
+            return t
+        missing = [k for k in default if k not in cols]
+        if missing:
+            raise ValueError(f'column map lacks {missing}')
+        order = [cols[k] for k in sorted(default, key=default.get)]
+        return t[..., order]
+
+    def forward(self, buses, lines, generators, B=None, L=None, G=None):
+        params = self._ensure_flat()
+        dev = params[0].device
+        if dev.type != 'cuda':
+            raise GNSError('the GNS hot path runs on a ROCm device only: call model.to("cuda") first '
+                           '(there is no CPU fallback)')
+        single = buses.dim() == 2
+        if single:
+            if lines.dim() != 2 or generators.dim() != 2:
+                raise ValueError('buses, lines, generators must all be 2-D (one grid) or all 3-D (a batch)')
+            buses, lines, generators = buses.unsqueeze(0), lines.unsqueeze(0), generators.unsqueeze(0)
+        if not (buses.dim() == lines.dim() == generators.dim() == 3):
+            raise ValueError('buses, lines, generators must all be 2-D (one grid) or all 3-D (a batch)')
+        if not (buses.shape[0] == lines.shape[0] == generators.shape[0]) or buses.shape[0] == 0:
+            raise ValueError('batch sizes of buses, lines, generators differ (or are zero)')
+        in_dev = buses.device
+        buses, lines, generators = self._remap(buses, B, _B0), self._remap(lines, L, _L0), self._remap(generators, G, _G0)
+        if buses.shape[-1] != 6 or lines.shape[-1] != 7 or generators.shape[-1] != 7:
+            raise ValueError('expected buses[...,6], lines[...,7], generators[...,7] (GNS/utils.py:4-13)')
+        for name, t in (('buses', buses), ('lines', lines), ('generators', generators)):
+            if t.dtype != torch.float32:
+                raise ValueError(f'{name} must be float32')
+        buses = buses.to(dev).contiguous()
+        lines = lines.to(dev).contiguous()
+        generators = generators.to(dev).contiguous()
+        topo = self._topology(lines, generators, buses.shape[1])
+        v, theta, total, last = _GNSFunction.apply(self, topo, buses, lines, generators, *params)
+        if in_dev != dev:
+            v, theta, total, last = v.to(in_dev), theta.to(in_dev), total.to(in_dev), last.to(in_dev)
+        if single:
+            return v[0], theta[0], total[0], last[0]
+        return v, theta, total, last
