@@ -81,3 +81,43 @@ extern "C" int gns_forward(const gns_config* cfg, const void* topo_dev, const fl
   A.part_idx = gns_part_index(GNS_FWD_THREADS / 64);
   return gns_launch_forward(d, h, cfg->multiple_phi, A, GNS_FWD_THREADS, st);
 }
+
+extern "C" int gns_backward(const gns_config* cfg, const void* topo_dev, const float* params, int64_t Bt,
+                            const void* fwd_workspace, size_t fwd_workspace_bytes, const float* grad_total,
+                            const float* grad_last, const float* grad_v, const float* grad_theta, float* grad_params,
+                            void* bwd_workspace, size_t bwd_workspace_bytes, void* stream) {
+  int rc = check_cfg(cfg);
+  if (rc != GNS_OK) return rc;
+  if (!topo_dev || !params || !fwd_workspace || !grad_params || !bwd_workspace || Bt <= 0) return GNS_EINVAL;
+  if (!dims_supported(cfg->latent_dim, cfg->hidden_dim) || cfg->K > GNS_MAX_K) return GNS_EUNSUPPORTED;
+  const int N = cfg->n_bus, E = cfg->n_line, K = cfg->K, d = cfg->latent_dim, h = cfg->hidden_dim;
+  GnsFwdLayout L;
+  gns_fwd_layout(N, E, d, h, K, cfg->multiple_phi, Bt, 1, &L);
+  GnsBwdLayout B;
+  gns_bwd_layout(N, E, d, h, K, cfg->multiple_phi, Bt, &B);
+  if (fwd_workspace_bytes < L.total || bwd_workspace_bytes < B.total) return GNS_ESIZE;
+  GnsFamilies fam; gns_families(d, h, K, cfg->multiple_phi, &fam);
+  hipStream_t st = (hipStream_t)stream;
+  const char* fw = (const char*)fwd_workspace;
+  char* bw = (char*)bwd_workspace;
+  const int blocks = (int)(B.groups < GNS_BWD_MAX_WG ? B.groups : GNS_BWD_MAX_WG);
+  const long long nslab = (long long)blocks * GNS_BWD_WAVES;
+  if (hipMemsetAsync(bw + B.off_slab, 0, (size_t)nslab * B.slab_floats * 4, st) != hipSuccess) return GNS_ELAUNCH;
+  GnsBwdArgs A;
+  std::memset(&A, 0, sizeof(A));
+  A.topo = (const int*)topo_dev;
+  A.pt = (const float*)(fw + L.off_pt); A.pn = (const float*)(fw + L.off_pn); A.in = (const float*)(fw + L.off_in);
+  A.state = (const float*)(fw + L.off_state); A.lam = (const float*)(fw + L.off_lam);
+  A.g_total = grad_total; A.g_last = grad_last; A.g_v = grad_v; A.g_theta = grad_theta;
+  A.adj = (float*)(bw + B.off_adj); A.slots = (float*)(bw + B.off_slots); A.slab = (float*)(bw + B.off_slab);
+  for (int i = 0; i < fam.nfam; ++i) {
+    A.t_off[i] = fam.t_off[i]; A.t_sz[i] = fam.t_sz[i]; A.n_off[i] = fam.n_off[i]; A.n_sz[i] = fam.n_sz[i];
+    A.f_off[i] = fam.flat_off[i]; A.f_sz[i] = fam.flat_sz[i];
+  }
+  for (int k = 0; k < K; ++k) A.gw[k] = (float)std::pow((double)cfg->gamma, (double)(K - k));
+  A.Bt = Bt; A.G = B.groups; A.slab_floats = B.slab_floats; A.N = N; A.E = E; A.K = K;
+  A.part_idx = gns_part_index(GNS_BWD_WAVES);
+  rc = gns_launch_backward(d, h, cfg->multiple_phi, A, blocks, st);
+  if (rc != GNS_OK) return rc;
+  return gns_launch_reduce(A.slab, (float*)(bw + B.off_part), grad_params, nslab, B.slab_floats, fam.flat_total, st);
+}

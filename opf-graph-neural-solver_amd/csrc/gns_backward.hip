@@ -1,6 +1,394 @@
-// placeholder: the fused reverse pass is added next
+// Fused reverse pass of the GNS K-step loop: what autograd does for total_loss.backward()
+// (GNS/main.py:288) through GNS.forward (main.py:140-202), hand-derived, for gfx950.
+//
+// Same ownership as the forward kernel: lane = grid, wave = 64 grids, the 8 waves of a workgroup split
+// the buses.  Per reverse step k:
+//   Pb-0    adjoint of delta_p_{k+1} is completed (loss term) and the scalar adjoint of lambda is reduced
+//   Pb-edge per line: adjoints of the line physics w.r.t. v, theta of its 2 (+4 bus-id-as-line-index) buses,
+//           stored per line (no atomics); every bus later gathers its own lists in a fixed order
+//   Ub      per bus: gather, then the update step is recomputed and back-propagated; the weight gradient
+//           (a contraction over the 64 grids of the wave) goes through an LDS transpose into a
+//           weight-stationary 4x4 register tile per lane and is accumulated into a per-wave slab.
+// delta_q carries no gradient: it is qg_new - Qd + Bs v^2 + (the very sums qg_new was built from), i.e.
+// identically zero as a function of (v, theta) (main.py:64-76 vs :83,98-103).
+#include "gns_device.h"
 #include "gns_kernels.h"
-extern "C" int gns_backward(const gns_config*, const void*, const float*, int64_t, const void*, size_t, const float*, const float*,
-                            const float*, const float*, float*, void*, size_t, void*) {
+
+// ---- LDS record of one row (one bus or one line of one grid) for one LearningBlock ---------------------
+template <int IN, int H, int OUT>
+struct RecLay {
+  static constexpr int XP = (IN + 1 + 3) / 4 * 4;   // x | 1 | 0..      (the 1 yields the bias gradient)
+  static constexpr int HP = (H + 1 + 3) / 4 * 4;    // a | 1 | 0..  and  g | 0..
+  static constexpr int GP = (OUT + 3) / 4 * 4;      // g3 | 0..
+  static constexpr int oX = 0, oA1 = XP, oA2 = oA1 + HP, oG1 = oA2 + HP, oG2 = oG1 + HP, oG3 = oG2 + HP;
+  static constexpr int raw = oG3 + GP;
+  static constexpr int RS = ((raw / 4) | 1) * 4;    // RS/4 odd: 16-byte row writes of 8 lanes hit 8 different bank quads
+  static constexpr int TX = XP / 4, TH = HP / 4, TG = GP / 4;
+  static constexpr int T1 = TH * TX, T2 = TH * TH, T4 = TG * TH, NT = T1 + T2 + T4;   // 4x4 tiles of dW1|db1, dW2|db2, dW4|db4
+  static_assert(NT <= 64, "one pass per network");
+};
+#define GNS_REC_ROWS 32
+constexpr int gns_cmax(int a, int b) { return a > b ? a : b; }
+
+template <int N, int I>
+__device__ __forceinline__ float pick(const float (&x)[N]) { return x[I]; }
+
+template <int IN, int H, int OUT, int OUTP>
+__device__ __forceinline__ void rec_write(float* rec, int row, const float (&x)[IN], const f2 (&a1)[H / 2], const f2 (&a2)[H / 2],
+                                          const f2 (&g1)[H / 2], const f2 (&g2)[H / 2], const f2 (&g3)[OUTP / 2]) {
+  using R = RecLay<IN, H, OUT>;
+  f4* dst = reinterpret_cast<f4*>(rec + row * R::RS);
+  static_for<0, R::raw / 4>([&](auto q_) {
+    constexpr int q = decltype(q_)::value;
+    float e[4];
+    static_for<0, 4>([&](auto c_) {
+      constexpr int c = decltype(c_)::value;
+      constexpr int o = 4 * q + c;
+      if constexpr (o < R::oA1) {
+        if constexpr (o < IN) e[c] = x[o]; else e[c] = (o == IN) ? 1.f : 0.f;
+      } else if constexpr (o < R::oA2) {
+        constexpr int i = o - R::oA1;
+        if constexpr (i < H) e[c] = lane_of<i>(a1); else e[c] = (i == H) ? 1.f : 0.f;
+      } else if constexpr (o < R::oG1) {
+        constexpr int i = o - R::oA2;
+        if constexpr (i < H) e[c] = lane_of<i>(a2); else e[c] = (i == H) ? 1.f : 0.f;
+      } else if constexpr (o < R::oG2) {
+        constexpr int i = o - R::oG1;
+        if constexpr (i < H) e[c] = lane_of<i>(g1); else e[c] = 0.f;
+      } else if constexpr (o < R::oG3) {
+        constexpr int i = o - R::oG2;
+        if constexpr (i < H) e[c] = lane_of<i>(g2); else e[c] = 0.f;
+      } else {
+        constexpr int i = o - R::oG3;
+        if constexpr (i < OUT) e[c] = lane_of<i>(g3); else e[c] = 0.f;
+      }
+    });
+    dst[q] = f4{e[0], e[1], e[2], e[3]};
+  });
+}
+
+// Weight gradient of one LearningBlock for the 64 grids of this wave (dW += sum_grids g (x) input), flat layout
+// W1[H][IN] b1[H] W2[H][H] b2[H] W4[OUT][H] b4[OUT] at slab_blk.  Lane t < NT owns the 4x4 tile t.
+template <int IN, int H, int OUT, int OUTP>
+__device__ __forceinline__ void dw_net(float* rec, int lane, float* slab_blk, const float (&x)[IN], const f2 (&a1)[H / 2],
+                                       const f2 (&a2)[H / 2], const f2 (&g1)[H / 2], const f2 (&g2)[H / 2],
+                                       const f2 (&g3)[OUTP / 2]) {
+  using R = RecLay<IN, H, OUT>;
+  int kind, cb, ib, woff, uoff;
+  {
+    int t = lane < R::NT ? lane : 0;
+    if (t < R::T1) { kind = 0; cb = t / R::TX; ib = t % R::TX; woff = R::oG1 + 4 * cb; uoff = R::oX + 4 * ib; }
+    else if (t < R::T1 + R::T2) { t -= R::T1; kind = 1; cb = t / R::TH; ib = t % R::TH; woff = R::oG2 + 4 * cb; uoff = R::oA1 + 4 * ib; }
+    else { t -= R::T1 + R::T2; kind = 2; cb = t / R::TH; ib = t % R::TH; woff = R::oG3 + 4 * cb; uoff = R::oA2 + 4 * ib; }
+  }
+  f2 acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) { acc[a][0] = f2{0.f, 0.f}; acc[a][1] = f2{0.f, 0.f}; }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if ((lane >> 5) == half) rec_write<IN, H, OUT, OUTP>(rec, lane & 31, x, a1, a2, g1, g2, g3);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const float* rw = rec + woff;
+    const float* ru = rec + uoff;
+#pragma unroll 8
+    for (int r = 0; r < GNS_REC_ROWS; ++r) {
+      const f4 w = *reinterpret_cast<const f4*>(rw + r * R::RS);
+      const f4 u = *reinterpret_cast<const f4*>(ru + r * R::RS);
+      const f2 u0 = f2{u.x, u.y}, u1 = f2{u.z, u.w};
+      acc[0][0] = __builtin_elementwise_fma(splat(w.x), u0, acc[0][0]); acc[0][1] = __builtin_elementwise_fma(splat(w.x), u1, acc[0][1]);
+      acc[1][0] = __builtin_elementwise_fma(splat(w.y), u0, acc[1][0]); acc[1][1] = __builtin_elementwise_fma(splat(w.y), u1, acc[1][1]);
+      acc[2][0] = __builtin_elementwise_fma(splat(w.z), u0, acc[2][0]); acc[2][1] = __builtin_elementwise_fma(splat(w.z), u1, acc[2][1]);
+      acc[3][0] = __builtin_elementwise_fma(splat(w.w), u0, acc[3][0]); acc[3][1] = __builtin_elementwise_fma(splat(w.w), u1, acc[3][1]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane < R::NT) {
+    constexpr int ob1 = IN * H, oW2 = ob1 + H, ob2 = oW2 + H * H, oW4 = ob2 + H, ob4 = oW4 + OUT * H;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int c = 4 * cb + a;
+#pragma unroll
+      for (int bq = 0; bq < 4; ++bq) {
+        const int i = 4 * ib + bq;
+        const float val = (bq & 1) ? acc[a][bq >> 1].y : acc[a][bq >> 1].x;
+        int idx = -1;
+        if (kind == 0) { if (c < H) idx = (i < IN) ? c * IN + i : (i == IN ? ob1 + c : -1); }
+        else if (kind == 1) { if (c < H) idx = (i < H) ? oW2 + c * H + i : (i == H ? ob2 + c : -1); }
+        else { if (c < OUT) idx = (i < H) ? oW4 + c * H + i : (i == H ? ob4 + c : -1); }
+        if (idx >= 0) slab_blk[idx] += val;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int D, int H, bool MULTI>
+__global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArgs A) {
+  using C = GnsDims<D, H, MULTI>;
+  constexpr int RB = C::RB;
+  constexpr int W = GNS_BWD_WAVES;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int N = A.N, E = A.E, K = A.K;
+  cip topo = (cip)A.topo;
+  cfp PT = (cfp)A.pt;
+  cfp PN = (cfp)A.pn;
+  const cip in_ptr = topo + topo[TH_IN_PTR], in_src = topo + topo[TH_IN_SRC], in_dst = topo + topo[TH_IN_DST],
+            in_a = topo + topo[TH_IN_A], in_b = topo + topo[TH_IN_B], out_ptr = topo + topo[TH_OUT_PTR],
+            out_c = topo + topo[TH_OUT_C], out_d = topo + topo[TH_OUT_D], is_gen = topo + topo[TH_IS_GEN],
+            p2q = topo + topo[TH_P2Q], q2p = topo + topo[TH_Q2P], incd_ptr = topo + topo[TH_INCD_PTR],
+            incd = topo + topo[TH_INCD], part = topo + topo[TH_PART] + A.part_idx * (GNS_MAXW + 1),
+            epart = topo + topo[TH_EPART] + A.part_idx * (GNS_MAXW + 1);
+  const int n0 = part[wave], n1 = part[wave + 1];
+  const int e0 = epart[wave], e1 = epart[wave + 1];
+  const long long R = gns_in_rows(N, E);
+  const float* IN = A.in;
+
+  constexpr int RECF = GNS_REC_ROWS * gns_cmax(gns_cmax(RecLay<C::L_IN, H, D>::RS, RecLay<C::L_IN, H, 1>::RS),
+                                                 RecLay<C::PHI_IN, H, C::PHI_OUT>::RS);
+  __shared__ __attribute__((aligned(16))) float rec_all[W][RECF];
+  __shared__ float red[2][W][GNS_LANES];
+  float* rec = rec_all[wave];
+  float* slab = A.slab + ((long long)blockIdx.x * W + wave) * A.slab_floats;
+  const float invN = 1.0f / (float)N;
+
+  for (long long g = blockIdx.x; g < A.G; g += gridDim.x) {
+    const long long in_base = g * R, row_ein = in_base + 3LL * N, row_eout = row_ein + 3LL * E, row_grid = row_eout + E;
+    const long long b = g * GNS_LANES + lane;
+    const bool live = b < A.Bt;
+    const float gt = (live && A.g_total) ? A.g_total[b] : 0.f;
+    const float gl = (live && A.g_last) ? A.g_last[b] : 0.f;
+    auto state_row = [&](int slot, int n) { return (((long long)slot * A.G + g) * N + n) * RB; };
+    auto adj_row = [&](int n) { return (g * N + n) * RB; };
+    auto slot_ptr = [&](int j, int p) { return A.slots + ((g * 6 + j) * E + p) * GNS_LANES + lane; };
+    const f4 gsum = *row_ptr(IN, row_grid, lane);
+
+    // adjoints of the outputs: v_out = where(v < 0, 0, v) (main.py:201), theta_out = theta
+    for (int n = n0; n < n1; ++n) {
+      const f4 sK = *row_ptr(A.state, state_row(K, n), lane);
+      const float vb = (live && A.g_v) ? ((sK.x < 0.f) ? 0.f : A.g_v[b * N + n]) : 0.f;
+      const float tb = (live && A.g_theta) ? A.g_theta[b * N + n] : 0.f;
+      const long long ar = adj_row(n);
+      *row_ptr(A.adj, ar, lane) = f4{vb, tb, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < C::MQ; ++q) *row_ptr(A.adj, ar + 1 + q, lane) = f4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (int k = K - 1; k >= 0; --k) {
+      const long long koff = k;
+      // d total / d dp_{k+1}[n] = g_total * gamma^(K-k) * 2 dp / N  (+ g_last * 2 dp / N after the last step)  main.py:198-199
+      const float cdp = 2.f * (gt * A.gw[k] + (k == K - 1 ? gl : 0.f)) * invN;
+      const f2 lamv = reinterpret_cast<const f2*>(A.lam)[((long long)k * A.G + g) * GNS_LANES + lane];
+      const int bits = (int)lamv.y;
+      const bool low1 = bits & 1, low2 = bits & 2;
+
+      // ---------------- Pb-0 ----------------
+      float lb = 0.f;
+      for (int n = n0; n < n1; ++n) {
+        const f4 s1 = *row_ptr(A.state, state_row(k + 1, n), lane);
+        f4 a0 = *row_ptr(A.adj, adj_row(n), lane);
+        a0.z = a0.z + cdp * s1.z;
+        *row_ptr(A.adj, adj_row(n), lane) = a0;
+        const f4 b1 = *row_ptr(IN, in_base + 3LL * n + 1, lane);            // Pmin,Pset,Pmax per bus
+        lb += a0.z * (low2 ? 2.f * (b1.y - b1.x) : 2.f * (b1.z - b1.y));    // d Pg_new / d lambda  (main.py:53-57)
+      }
+      red[k & 1][wave][lane] = lb;
+      __syncthreads();
+      float lbar = 0.f;
+#pragma unroll
+      for (int w = 0; w < W; ++w) lbar += red[k & 1][w][lane];
+      const float pgbar = lbar / (low1 ? 2.f * (gsum.y - gsum.z) : 2.f * (gsum.w - gsum.y));   // d lambda / d p_global (main.py:47-51)
+
+      // ---------------- Pb-edge ----------------
+      for (int p = e0; p < e1; ++p) {
+        const int s = in_src[p], t = in_dst[p], ia = in_a[p], ib = in_b[p], q = p2q[p], ic = out_c[q], id = out_d[q];
+        const f4 e1v = *row_ptr(IN, row_ein + 3LL * p + 1, lane);           // shift_e, y_s, tau_s, sh_s
+        const f4 o0 = *row_ptr(IN, row_eout + q, lane);                      // y_t, tau_t, sh_t, b_t
+        const f4 ss = *row_ptr(A.state, state_row(k + 1, s), lane), st = *row_ptr(A.state, state_row(k + 1, t), lane);
+        const float tha = row_ptr(A.state, state_row(k + 1, ia), lane)->y, thb = row_ptr(A.state, state_row(k + 1, ib), lane)->y;
+        const float thc = row_ptr(A.state, state_row(k + 1, ic), lane)->y, thd = row_ptr(A.state, state_row(k + 1, id), lane)->y;
+        const float Fb = row_ptr(A.adj, adj_row(t), lane)->z;                // dp[t] += p_from   (main.py:94)
+        const float Tb = row_ptr(A.adj, adj_row(s), lane)->z;                // dp[s] += p_to     (main.py:95)
+        const float vs = ss.x, ths = ss.y, vt = st.x, tht = st.y;
+        const float ys = e1v.y, taus = e1v.z, shs = e1v.w;
+        const float dl = tha - thb, dl2 = thd - thc;
+        float sA, cA, sB, cB, sD, cD, sC, cC, sD2, cD2;
+        sincosf(ths - tht - dl - shs, &sA, &cA);
+        sincosf(tht - ths - dl + shs, &sB, &cB);
+        sincosf(dl, &sD, &cD);
+        sincosf(tht - ths - dl2 - o0.z, &sC, &cC);
+        sincosf(dl2, &sD2, &cD2);
+        // "from" expressions: p_from (main.py:91) and |msg| of the joule loss (main.py:41)
+        const float yot = ys / taus, yot2 = ys / (taus * taus);
+        const float base = vs * vt * yot;
+        const float kJ = vs * yot2 + vt * vt * ys;
+        const float inner = base * (sA + sB) + kJ * sD;
+        const float Jb = pgbar * (inner > 0.f ? 1.f : (inner < 0.f ? -1.f : 0.f));
+        float dvs = Fb * (vt * yot * sA + 2.f * vs * yot2 * sD) + Jb * (vt * yot * (sA + sB) + yot2 * sD);
+        float dvt = Fb * (vs * yot * sA) + Jb * (vs * yot * (sA + sB) + 2.f * vt * ys * sD);
+        const float Ab = (Fb + Jb) * base * cA, Bb = Jb * base * cB;
+        const float dbar = Fb * (vs * vs * yot2) * cD + Jb * kJ * cD - Ab - Bb;
+        float dths = Ab - Bb, dtht = Bb - Ab;
+        // "to" expression: p_to (main.py:92)
+        const float yot_t = o0.x / o0.y;
+        const float base2 = vt * vs * yot_t;
+        dvt += Tb * (vs * yot_t * sC + 2.f * vt * o0.x * sD2);
+        dvs += Tb * (vt * yot_t * sC);
+        const float Cb = Tb * base2 * cC;
+        const float dbar2 = Tb * vt * vt * o0.x * cD2 - Cb;
+        dtht += Cb; dths -= Cb;
+        *slot_ptr(0, p) = dvs; *slot_ptr(1, p) = dvt; *slot_ptr(2, p) = dths; *slot_ptr(3, p) = dtht;
+        *slot_ptr(4, p) = dbar; *slot_ptr(5, p) = dbar2;
+      }
+      __syncthreads();
+
+      // ---------------- Ub ----------------
+      for (int n = n0; n < n1; ++n) {
+        const long long ar = adj_row(n);
+        const f4 a0 = *row_ptr(A.adj, ar, lane);
+        float vbar = a0.x, thbar = a0.y;
+        const float dpb = a0.z;
+        float mbar[D];
+        load_vec<D>(A.adj, ar + 1, lane, mbar);
+        const int p0 = in_ptr[n], p1 = in_ptr[n + 1];
+        for (int p = p0; p < p1; ++p) { vbar += *slot_ptr(1, p); thbar += *slot_ptr(3, p); }
+        const int q0 = out_ptr[n], q1 = out_ptr[n + 1];
+        for (int q = q0; q < q1; ++q) { const int p = q2p[q]; vbar += *slot_ptr(0, p); thbar += *slot_ptr(2, p); }
+        const int i0 = incd_ptr[n], i1 = incd_ptr[n + 1];
+        for (int i = i0; i < i1; ++i) {
+          const int code = incd[i];
+          const float val = *slot_ptr((code & 2) ? 5 : 4, code >> 2);
+          thbar += (code & 1) ? -val : val;
+        }
+        {
+          const f4 s1 = *row_ptr(A.state, state_row(k + 1, n), lane);
+          const float Gs = row_ptr(IN, in_base + 3LL * n, lane)->z;
+          vbar += (pgbar - dpb) * (2.f * Gs * s1.x);     // -Gs v^2 in dp (main.py:82) and +Gs v^2 in p_global (main.py:45)
+        }
+        // recompute the update step k of this bus (main.py:155-188)
+        const long long rr = state_row(k, n);
+        const f4 s0 = *row_ptr(A.state, rr, lane);
+        float m[D];
+        load_vec<D>(A.state, rr + 1, lane, m);
+        f2 S[C::NPHI][C::PHI_OUTP / 2];
+#pragma unroll
+        for (int f = 0; f < C::NPHI; ++f)
+#pragma unroll
+          for (int j = 0; j < C::PHI_OUTP / 2; ++j) S[f][j] = f2{0.f, 0.f};
+        for (int p = p0; p < p1; ++p) {
+          const f4 ea = *row_ptr(IN, row_ein + 3LL * p, lane), eb = *row_ptr(IN, row_ein + 3LL * p + 1, lane);
+          float x[C::PHI_IN];
+#pragma unroll
+          for (int i = 0; i < D; ++i) x[i] = m[i];
+          x[D] = ea.x; x[D + 1] = ea.y; x[D + 2] = ea.z; x[D + 3] = ea.w; x[D + 4] = eb.x;
+          static_for<0, C::NPHI>([&](auto f_) {
+            constexpr int f = decltype(f_)::value;
+            f2 a1[H / 2], a2[H / 2], y[C::PHI_OUTP / 2];
+            mlp_fwd<C::PHI_IN, H, C::PHI_OUTP>(PT + A.t_off[f] + koff * A.t_sz[f], x, a1, a2, y);
+#pragma unroll
+            for (int j = 0; j < C::PHI_OUTP / 2; ++j) S[f][j] += y[j];
+          });
+        }
+        constexpr int HEAD = (4 + D) / 2;            // pairs of [v theta dp dq | m]
+        f2 xs[HEAD];
+#pragma unroll
+        for (int j = 0; j < HEAD; ++j) xs[j] = f2{0.f, 0.f};
+        f2 gS[C::NPHI][C::PHI_OUTP / 2];
+#pragma unroll
+        for (int f = 0; f < C::NPHI; ++f)
+#pragma unroll
+          for (int j = 0; j < C::PHI_OUTP / 2; ++j) gS[f][j] = f2{0.f, 0.f};
+        const float vgate = is_gen[n] ? 0.f : vbar;   // v only moves on buses without a generator (main.py:184-186)
+        static_for<0, 3>([&](auto l_) {
+          constexpr int l = decltype(l_)::value;
+          constexpr int fphi = MULTI ? (l == 0 ? 1 : (l == 1 ? 0 : 2)) : 0;
+          constexpr int OUT = (l == 2) ? D : 1, OUTP = OUT + (OUT & 1);
+          float x[C::L_IN];
+          x[0] = s0.x; x[1] = s0.y; x[2] = s0.z; x[3] = s0.w;
+#pragma unroll
+          for (int i = 0; i < D; ++i) x[4 + i] = m[i];
+          static_for<0, D>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            if constexpr (MULTI) x[4 + D + i] = lane_of<i>(S[fphi]);
+            else x[4 + D + i] = (i == 0) ? S[0][0].x : 0.f;
+          });
+          f2 a1[H / 2], a2[H / 2], y[OUTP / 2], g3[OUTP / 2], g2[H / 2], g1[H / 2], gx[C::L_IN / 2];
+          mlp_fwd<C::L_IN, H, OUTP>(PT + A.t_off[C::NPHI + l] + koff * A.t_sz[C::NPHI + l], x, a1, a2, y);
+          if constexpr (l == 0) g3[0] = f2{thbar, 0.f};
+          else if constexpr (l == 1) g3[0] = f2{vgate, 0.f};
+          else static_for<0, D / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; g3[j] = f2{mbar[2 * j], mbar[2 * j + 1]}; });
+          mlp_bwd<C::L_IN, H, OUTP, C::L_IN>(PN + A.n_off[C::NPHI + l] + koff * A.n_sz[C::NPHI + l], a1, a2, g3, g2, g1, gx);
+#pragma unroll
+          for (int j = 0; j < HEAD; ++j) xs[j] += gx[j];
+          if constexpr (MULTI) {
+#pragma unroll
+            for (int j = 0; j < D / 2; ++j) gS[fphi][j] = gx[HEAD + j];
+          } else {
+            gS[0][0].x += gx[HEAD].x;
+          }
+          dw_net<C::L_IN, H, OUT, OUTP>(rec, lane, slab + A.f_off[C::NPHI + l] + koff * A.f_sz[C::NPHI + l], x, a1, a2, g1, g2, g3);
+        });
+        float mnew[D];
+        static_for<0, D>([&](auto i_) { constexpr int i = decltype(i_)::value; mnew[i] = mbar[i] + lane_of<4 + i>(xs); });
+        for (int p = p0; p < p1; ++p) {                  // back through the messages of the lines ending at n
+          const f4 ea = *row_ptr(IN, row_ein + 3LL * p, lane), eb = *row_ptr(IN, row_ein + 3LL * p + 1, lane);
+          float x[C::PHI_IN];
+#pragma unroll
+          for (int i = 0; i < D; ++i) x[i] = m[i];
+          x[D] = ea.x; x[D + 1] = ea.y; x[D + 2] = ea.z; x[D + 3] = ea.w; x[D + 4] = eb.x;
+          static_for<0, C::NPHI>([&](auto f_) {
+            constexpr int f = decltype(f_)::value;
+            f2 a1[H / 2], a2[H / 2], y[C::PHI_OUTP / 2], g2[H / 2], g1[H / 2], gx[D / 2];
+            mlp_fwd<C::PHI_IN, H, C::PHI_OUTP>(PT + A.t_off[f] + koff * A.t_sz[f], x, a1, a2, y);
+            mlp_bwd<C::PHI_IN, H, C::PHI_OUTP, D>(PN + A.n_off[f] + koff * A.n_sz[f], a1, a2, gS[f], g2, g1, gx);
+            static_for<0, D>([&](auto i_) { constexpr int i = decltype(i_)::value; mnew[i] += lane_of<i>(gx); });
+            dw_net<C::PHI_IN, H, C::PHI_OUT, C::PHI_OUTP>(rec, lane, slab + A.f_off[f] + koff * A.f_sz[f], x, a1, a2, g1, g2, gS[f]);
+          });
+        }
+        *row_ptr(A.adj, ar, lane) = f4{vbar + xs[0].x, thbar + xs[0].y, xs[1].x, 0.f};   // main.py:182,186 identity paths
+        store_vec<D>(A.adj, ar + 1, lane, mnew);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---- slab reduction: grad[i] += sum over slabs, two fixed-order stages (bitwise reproducible) ----------
+__global__ void gns_reduce_stage1(const float* __restrict__ slab, float* __restrict__ part, long long nslab, long long sf) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= sf) return;
+  const long long j = blockIdx.y, s0 = nslab * j / GNS_RED_PARTS, s1 = nslab * (j + 1) / GNS_RED_PARTS;
+  float acc = 0.f;
+  for (long long s = s0; s < s1; ++s) acc += slab[s * sf + i];
+  part[j * sf + i] = acc;
+}
+__global__ void gns_reduce_stage2(const float* __restrict__ part, float* __restrict__ grad, long long sf, long long nparam) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nparam) return;
+  float acc = 0.f;
+  for (int j = 0; j < GNS_RED_PARTS; ++j) acc += part[j * sf + i];
+  grad[i] += acc;
+}
+
+template <int D, int H, bool MULTI>
+static int launch_backward_t(const GnsBwdArgs& A, int blocks, hipStream_t st) {
+  hipLaunchKernelGGL((gns_backward_kernel<D, H, MULTI>), dim3(blocks), dim3(GNS_BWD_THREADS), 0, st, A);
+  return hipGetLastError() == hipSuccess ? GNS_OK : GNS_ELAUNCH;
+}
+
+int gns_launch_backward(int d, int h, int multi, const GnsBwdArgs& A, int blocks, hipStream_t st) {
+#define GNS_CASE(DD, HH)                                                                      \
+  if (d == DD && h == HH) return multi ? launch_backward_t<DD, HH, true>(A, blocks, st)       \
+                                       : launch_backward_t<DD, HH, false>(A, blocks, st);
+  GNS_FOR_EACH_DIMS(GNS_CASE)
+#undef GNS_CASE
   return GNS_EUNSUPPORTED;
+}
+
+int gns_launch_reduce(const float* slab, float* part, float* grad, long long nslab, long long sf, long long nparam, hipStream_t st) {
+  hipLaunchKernelGGL(gns_reduce_stage1, dim3((unsigned)((sf + 255) / 256), GNS_RED_PARTS), dim3(256), 0, st, slab, part, nslab, sf);
+  hipLaunchKernelGGL(gns_reduce_stage2, dim3((unsigned)((nparam + 255) / 256)), dim3(256), 0, st, part, grad, sf, nparam);
+  return hipGetLastError() == hipSuccess ? GNS_OK : GNS_ELAUNCH;
 }

@@ -43,6 +43,7 @@ enum {
   TH_EPART,     // [GNS_NPART][GNS_MAXW+1] ranges of in-edge positions per wave (backward, edge-centric)
   TH_INCD_PTR,  // [N+1] incidence list of the delta adjoints (backward)
   TH_INCD,      // [4E]  p*4 + code ; code 0:+dbar 1:-dbar 2:+dbar' 3:-dbar'
+  TH_IN_DST,    // [E]   t = dst[e] of in-edge p
   TH_TOTAL,     // blob length in words
   TH_HDR_WORDS = 32
 };
@@ -118,13 +119,15 @@ static inline void gns_fwd_layout(int N, int E, int d, int h, int K, int multi, 
 }
 
 // ---- backward workspace layout ------------------------------------------------------------------------
+#define GNS_BWD_WAVES 8        // waves per backward workgroup
+#define GNS_RED_PARTS 16       // first-stage partial sums of the slab reduction
 struct GnsBwdLayout {
   int64_t groups, mq, rows_bus;
   int64_t slab_floats;     // per-wave gradient slab: one float per flat parameter
   int64_t nslab;           // number of slabs (workgroups x waves)
-  size_t off_adj, off_slots, off_slab, total;
+  size_t off_adj, off_slots, off_slab, off_part, total;
 };
-#define GNS_BWD_MAX_WG 512   // persistent backward workgroups (each loops over grid groups)
+#define GNS_BWD_MAX_WG 256   // persistent backward workgroups (each loops over grid groups)
 
 static inline void gns_bwd_layout(int N, int E, int d, int h, int K, int multi, int64_t Bt, GnsBwdLayout* B) {
   GnsFamilies f; gns_families(d, h, K, multi, &f);
@@ -133,10 +136,11 @@ static inline void gns_bwd_layout(int N, int E, int d, int h, int K, int multi, 
   B->rows_bus = 1 + B->mq;
   B->slab_floats = (f.flat_total + 63) / 64 * 64;
   int64_t wg = B->groups < GNS_BWD_MAX_WG ? B->groups : GNS_BWD_MAX_WG;
-  B->nslab = wg * GNS_MAXW;
+  B->nslab = wg * GNS_BWD_WAVES;
   size_t o = 0;
   B->off_adj = o;   o = gns_align256(o + (size_t)B->groups * N * B->rows_bus * GNS_LANES * 16);   // (vbar,thbar,dpbar,-) + mbar
   B->off_slots = o; o = gns_align256(o + (size_t)B->groups * 6 * E * GNS_LANES * 4);               // 6 adjoint planes per line
   B->off_slab = o;  o = gns_align256(o + (size_t)B->nslab * B->slab_floats * 4);
+  B->off_part = o;  o = gns_align256(o + (size_t)GNS_RED_PARTS * B->slab_floats * 4);
   B->total = o;
 }

@@ -35,6 +35,24 @@ struct GnsFwdArgs {
   int N, E, K, save, zero, part_idx;
 };
 
+struct GnsBwdArgs {
+  const int* topo;
+  const float* pt; const float* pn;      // T-stream (recompute) and N-stream (data gradients) parameters
+  const float* in;                       // packed inputs
+  const float* state;                    // saved states S_0..S_K of the forward
+  const float* lam;                      // (lambda, branch bits) per step
+  const float* g_total; const float* g_last; const float* g_v; const float* g_theta;   // upstream gradients (nullable)
+  float* adj;                            // [G][N][RB][64] float4: (vbar, thbar, dpbar, -) + mbar
+  float* slots;                          // [G][6][E][64] per-line physics adjoints
+  float* slab;                           // [blocks*8][slab_floats] per-wave weight-gradient accumulators
+  long long t_off[6], t_sz[6], n_off[6], n_sz[6], f_off[6], f_sz[6];
+  float gw[GNS_MAX_K];
+  long long Bt, G, slab_floats;
+  int N, E, K, part_idx;
+};
+
+int gns_launch_backward(int d, int h, int multi, const GnsBwdArgs& A, int blocks, hipStream_t st);
+int gns_launch_reduce(const float* slab, float* part, float* grad, long long nslab, long long sf, long long nparam, hipStream_t st);
 int gns_launch_forward(int d, int h, int multi, const GnsFwdArgs& A, int threads, hipStream_t st);
 int gns_launch_pack_params(const float* flat, float* pt, float* pn, const GnsFamilies& fam, int K, int H, hipStream_t st);
 int gns_launch_pack_inputs(const int* topo, const float* buses, const float* lines, const float* gens, float* out, int N,

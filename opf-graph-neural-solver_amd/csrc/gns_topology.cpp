@@ -52,11 +52,11 @@ int build(int N, int E, int Gn, const int32_t* src, const int32_t* dst, const in
     std::vector<int32_t> ci(in_ptr.begin(), in_ptr.end() - 1), co(out_ptr.begin(), out_ptr.end() - 1);
     for (int e = 0; e < E; ++e) { in_eid[ci[dst[e]]++] = e; out_eid[co[src[e]]++] = e; }
   }
-  std::vector<int32_t> in_src(E), in_a(E), in_b(E), out_dst(E), out_c(E), out_d(E), p2q(E), q2p(E), pos_out(E);
+  std::vector<int32_t> in_src(E), in_dst(E), in_a(E), in_b(E), out_dst(E), out_c(E), out_d(E), p2q(E), q2p(E), pos_out(E);
   for (int q = 0; q < E; ++q) pos_out[out_eid[q]] = q;
   for (int p = 0; p < E; ++p) {
     const int e = in_eid[p], s = src[e];
-    in_src[p] = s; in_a[p] = src[s]; in_b[p] = dst[s];          // line NUMBER s
+    in_src[p] = s; in_dst[p] = dst[e]; in_a[p] = src[s]; in_b[p] = dst[s];          // line NUMBER s
     p2q[p] = pos_out[e]; q2p[pos_out[e]] = p;
   }
   for (int q = 0; q < E; ++q) {
@@ -102,7 +102,7 @@ int build(int N, int E, int Gn, const int32_t* src, const int32_t* dst, const in
   b.put(TH_OUT_PTR, out_ptr); b.put(TH_OUT_EID, out_eid); b.put(TH_OUT_DST, out_dst); b.put(TH_OUT_C, out_c); b.put(TH_OUT_D, out_d);
   b.put(TH_IS_GEN, is_gen); b.put(TH_GEN_PTR, gen_ptr); b.put(TH_GEN_IDX, gen_idx);
   b.put(TH_PART, part); b.put(TH_P2Q, p2q); b.put(TH_Q2P, q2p); b.put(TH_EPART, epart);
-  b.put(TH_INCD_PTR, incd_ptr); b.put(TH_INCD, incd);
+  b.put(TH_INCD_PTR, incd_ptr); b.put(TH_INCD, incd); b.put(TH_IN_DST, in_dst);
   b.w[TH_TOTAL] = (int32_t)b.w.size();
   out.swap(b.w);
   return GNS_OK;
@@ -110,7 +110,7 @@ int build(int N, int E, int Gn, const int32_t* src, const int32_t* dst, const in
 
 size_t blob_words(int N, int E, int Gn) {
   return TH_HDR_WORDS + 2 * (size_t)(N + 1) + 12 * (size_t)E + (size_t)N + (size_t)(N + 1) + (size_t)std::max(Gn, 1)
-         + 2 * (size_t)GNS_NPART * (GNS_MAXW + 1) + (size_t)(N + 1) + 4 * (size_t)E;
+         + 2 * (size_t)GNS_NPART * (GNS_MAXW + 1) + (size_t)(N + 1) + 5 * (size_t)E;
 }
 
 }  // namespace
