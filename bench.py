@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Benchmark of the GNS hot path on MI355X: grids/s for forward+backward on batched case118, K=4.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = one training step over a resident synthetic batch: fused forward, fused backward, ONE all-reduce of
+the flat gradient (N>1), Adam step.  Inputs are generated on the device before the timed region.  Rank 0 prints
+one JSON line (see DESIGN.md "Measurement" for every field).  At N=1 the line also carries the CPU baseline: the
+oracle (a torch-CPU restatement of the reference's per-grid forward/backward), one single-threaded process per
+core, on a bounded sample of the same workload - run BEFORE the GPU is initialised.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CASE, BATCH_PER_GPU, K, D, H, GAMMA, MULTI = 118, 16384, 4, 20, 10, 0.9, True
+BYTES_PER_GRID = 10504          # compulsory: every input element read once + every output written once
+MFLOP_FWD_PER_GRID = 4.19216    # nominal MLP flops of one forward (MACs x 2), reference formulation
+HBM_PEAK_GBS = 8000.0           # MI355X spec (MI355X_MICROARCH.md)
+FP32_PEAK_TFLOPS = 157.3
+
+
+def _cpu_worker(args):
+    """One single-threaded process: time the oracle's per-grid forward+backward (and forward only) for ~seconds."""
+    seconds, seed = args
+    import torch
+    torch.set_num_threads(1)
+    sys.path.insert(0, ROOT)
+    from oracle import gns_oracle as orc
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('synth_cpu', os.path.join(ROOT, 'opf-graph-neural-solver_amd', 'synth.py'))
+    synth = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(synth)
+    buses, lines, gens = synth.synth_grids(CASE, 8, seed=1000 + seed)
+    flat = orc.flatten_params(orc.init_params(D, H, K, MULTI, seed=0))
+    params = orc.unflatten_params(flat.clone().requires_grad_(True), D, H, K, MULTI)
+    kw = dict(latent_dim=D, K=K, gamma=GAMMA, multiple_phi=MULTI)
+    out = {}
+    for mode in ('fwd', 'fwd_bwd'):
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds * (0.3 if mode == 'fwd' else 0.7):
+            i = n % 8
+            if mode == 'fwd':
+                with torch.no_grad():
+                    orc.gns_forward(params, buses[i], lines[i], gens[i], **kw)
+            else:
+                _, _, tot, _ = orc.gns_forward(params, buses[i], lines[i], gens[i], **kw)
+                tot.backward()
+            n += 1
+        out[mode] = (n, time.perf_counter() - t0)
+    return out
+
+
+def cpu_baseline(seconds=14.0):
+    import multiprocessing as mp
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
+    ctx = mp.get_context('spawn')     # fresh interpreters; the parent has not touched the GPU yet
+    with ctx.Pool(cores) as pool:
+        res = pool.map(_cpu_worker, [(seconds, i) for i in range(cores)])
+    rate = {m: sum(r[m][0] / r[m][1] for r in res) for m in ('fwd', 'fwd_bwd')}
+    grids = sum(r['fwd_bwd'][0] for r in res)
+    return {'value': round(rate['fwd_bwd'], 1), 'unit': 'grids/s', 'cores': cores, 'kind': 'port',
+            'forward_only_grids_per_s': round(rate['fwd'], 1),
+            'sample': f'{grids} case118 grids (K=4, d=20, h=10, multiple_phi), one grid per call like GNS/main.py:279-288, '
+                      f'{cores} single-threaded processes x ~{seconds:.0f} s, torch {__import__("torch").__version__} CPU'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch-per-gpu', type=int, default=BATCH_PER_GPU)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    a = ap.parse_args()
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N')
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    import torch
+    import torch.distributed as dist
+    import ctypes
+    import opf_graph_neural_solver_amd as amd
+
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    lib = amd.load_library()
+
+    torch.manual_seed(0)                       # identical replicas on every rank
+    model = amd.GNS(latent_dim=D, hidden_dim=H, K=K, gamma=GAMMA, multiple_phi=MULTI).to(dev)
+    model.topology_check = 'first'             # id columns are verified once per case, not on every step
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)    # the reference's optimiser (GNS/main.py:243)
+    bt = a.batch_per_gpu
+    buses, lines, gens = amd.synth.synth_grids(CASE, bt, seed=1234 + rank, device=dev)   # resident before timing
+    Bc, Lc, Gc = amd.get_BLG()
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        v, th, tot, last = model(buses, lines, gens, Bc, Lc, Gc)
+        tot.mean().backward()
+        amd.dist.allreduce_gradients(model, global_batch=bt * world, local_batch=bt)
+        opt.step()
+        return tot
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        step()
+    lib.gns_profile_enable(max(a.steps, 1))
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        tot = step()
+    fence()
+    dt = time.perf_counter() - t0
+    ms_f, n_f, ms_b, n_b = ctypes.c_float(), ctypes.c_int(), ctypes.c_float(), ctypes.c_int()
+    lib.gns_profile_read(0, ctypes.byref(ms_f), ctypes.byref(n_f))
+    lib.gns_profile_read(1, ctypes.byref(ms_b), ctypes.byref(n_b))
+    lib.gns_profile_enable(0)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    # forward-only throughput (evaluation mode), not part of the headline value
+    with torch.no_grad():
+        for _ in range(2):
+            model(buses, lines, gens, Bc, Lc, Gc)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(max(a.steps // 2, 1)):
+            model(buses, lines, gens, Bc, Lc, Gc)
+        torch.cuda.synchronize(dev)
+        fwd_only = bt * max(a.steps // 2, 1) / (time.perf_counter() - t1)
+
+    if rank == 0:
+        grids = bt * world * a.steps
+        value = grids / dt
+        fwd_ms = ms_f.value / max(n_f.value, 1)
+        bwd_ms = ms_b.value / max(n_b.value, 1)
+        dom_ms, dom = (bwd_ms, 'gns_backward_kernel') if bwd_ms >= fwd_ms else (fwd_ms, 'gns_forward_kernel')
+        ach_gbs = BYTES_PER_GRID * bt / (dom_ms * 1e-3) / 1e9
+        dom_flop = (2.0 if dom == 'gns_backward_kernel' else 1.0) * MFLOP_FWD_PER_GRID * 1e6 * bt
+        traffic = None
+        pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(dom)
+            except Exception:
+                traffic = None
+        line = {
+            'metric': 'grids/sec (fwd+bwd) on batched case118, K=4', 'value': round(value, 1), 'unit': 'grids/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'case118-shaped grids (118 buses, 186 lines, 54 generators), batch {bt} per GPU, K=4, '
+                                   'latent_dim=20, hidden_dim=10, multiple_phi=True, gamma=0.9; step = fused forward + fused '
+                                   'backward + flat-gradient all-reduce + Adam',
+                       'global_batch': bt * world, 'parallelism': f'dp{world} (grid-sharded)'},
+            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': round(ach_gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': round(ach_gbs / HBM_PEAK_GBS, 5), 'traffic': traffic,
+                         'algorithmic_bytes_per_launch': BYTES_PER_GRID * bt, 'kernel_ms': round(dom_ms, 4)},
+            'roofline_fp32': {'bound': 'fp32 vector FMA (the binding one: ~400 flop/B)', 'kernel': dom,
+                              'achieved': round(dom_flop / (dom_ms * 1e-3) / 1e12, 3), 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                              'frac': round(dom_flop / (dom_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
+                              'nominal_flop_per_launch': dom_flop},
+            'kernels_ms': {'gns_forward_kernel': round(fwd_ms, 4), 'gns_backward_kernel': round(bwd_ms, 4)},
+            'forward_only_grids_per_s': round(fwd_only * world, 1),
+            'final_mean_total_loss': float(tot.mean().item()),
+        }
+        if cpu is not None:
+            line['cpu_baseline'] = cpu
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -90,6 +90,15 @@ int gns_backward(const gns_config* cfg, const void* topo_dev, const float* param
                  const float* grad_total, const float* grad_last, const float* grad_v, const float* grad_theta,
                  float* grad_params, void* bwd_workspace, size_t bwd_workspace_bytes, void* stream);
 
+/* ---- diagnostics (benchmarks only; not on the reference's interface) -------------------------------
+ * gns_profile_enable(capacity > 0): from now on gns_forward / gns_backward record a HIP event pair around
+ * their fused main kernel, on the caller's stream, into a ring of `capacity` pairs per direction (capacity 0
+ * switches it off and frees the events).  gns_profile_read waits for the recorded events, returns the summed
+ * kernel time in milliseconds and the number of launches since the last read, and rewinds the ring.
+ * Not graph-capturable and not thread-safe; leave it off in production. */
+int gns_profile_enable(int capacity);
+int gns_profile_read(int backward, float* ms_sum, int* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,6 +10,7 @@ library or without a ROCm device the forward raises.
 """
 from .gns import GNS, LearningBlock, get_BLG, GNSError
 from . import synth
+from . import dist
 from ._lib import load_library, library_path
 
-__all__ = ['GNS', 'LearningBlock', 'get_BLG', 'GNSError', 'synth', 'load_library', 'library_path']
+__all__ = ['GNS', 'LearningBlock', 'get_BLG', 'GNSError', 'synth', 'dist', 'load_library', 'library_path']

@@ -42,12 +42,14 @@ def load_library():
     lib.gns_workspace_bytes.argtypes = [cfgp, i64, ctypes.c_int, ctypes.POINTER(sz), ctypes.POINTER(sz)]
     lib.gns_forward.argtypes = [cfgp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, sz, ctypes.c_int, vp]
     lib.gns_backward.argtypes = [cfgp, vp, vp, i64, vp, sz, vp, vp, vp, vp, vp, vp, sz, vp]
-    for f in ('gns_param_count', 'gns_config_supported', 'gns_topology_bytes', 'gns_prepare_topology',
-              'gns_workspace_bytes', 'gns_forward', 'gns_backward'):
+    lib.gns_profile_enable.argtypes = [ctypes.c_int]
+    lib.gns_profile_read.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]
+    for f in ('gns_profile_enable', 'gns_profile_read', 'gns_param_count', 'gns_config_supported', 'gns_topology_bytes', 'gns_prepare_topology',
+              'gns_workspace_bytes', 'gns_forward', 'gns_backward', 'gns_profile_enable', 'gns_profile_read'):
         getattr(lib, f).restype = ctypes.c_int
     _LIB = lib
     return lib
 
 
 EXPORTS = ('gns_version', 'gns_param_count', 'gns_config_supported', 'gns_topology_bytes', 'gns_prepare_topology',
-           'gns_workspace_bytes', 'gns_forward', 'gns_backward')
+           'gns_workspace_bytes', 'gns_forward', 'gns_backward', 'gns_profile_enable', 'gns_profile_read')

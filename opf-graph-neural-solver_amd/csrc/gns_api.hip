@@ -18,6 +18,52 @@ static int check_cfg(const gns_config* c) {
   return GNS_OK;
 }
 
+// ---- optional kernel timing (diagnostics) ---------------------------------------------------------------
+#include <vector>
+namespace {
+struct ProfRing { std::vector<hipEvent_t> a, b; int used = 0; };
+ProfRing g_prof[2];
+int g_prof_cap = 0;
+void prof_mark(int which, bool start, hipStream_t st) {
+  if (g_prof_cap <= 0) return;
+  ProfRing& r = g_prof[which];
+  if (r.used >= g_prof_cap) return;
+  (void)hipEventRecord(start ? r.a[r.used] : r.b[r.used], st);
+  if (!start) ++r.used;
+}
+}  // namespace
+
+extern "C" int gns_profile_enable(int capacity) {
+  for (auto& r : g_prof) {
+    for (auto e : r.a) (void)hipEventDestroy(e);
+    for (auto e : r.b) (void)hipEventDestroy(e);
+    r.a.clear(); r.b.clear(); r.used = 0;
+  }
+  g_prof_cap = 0;
+  if (capacity < 0) return GNS_EINVAL;
+  for (auto& r : g_prof)
+    for (int i = 0; i < capacity; ++i) {
+      hipEvent_t x, y;
+      if (hipEventCreate(&x) != hipSuccess || hipEventCreate(&y) != hipSuccess) return GNS_ELAUNCH;
+      r.a.push_back(x); r.b.push_back(y);
+    }
+  g_prof_cap = capacity;
+  return GNS_OK;
+}
+
+extern "C" int gns_profile_read(int backward, float* ms_sum, int* launches) {
+  if (!ms_sum || !launches) return GNS_EINVAL;
+  ProfRing& r = g_prof[backward ? 1 : 0];
+  float tot = 0.f;
+  for (int i = 0; i < r.used; ++i) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.b[i]) != hipSuccess || hipEventElapsedTime(&ms, r.a[i], r.b[i]) != hipSuccess) return GNS_ELAUNCH;
+    tot += ms;
+  }
+  *ms_sum = tot; *launches = r.used; r.used = 0;
+  return GNS_OK;
+}
+
 extern "C" const char* gns_version(void) { return "gns_hip 0.1 gfx950"; }
 
 extern "C" int gns_param_count(const gns_config* cfg, int64_t* count) {
@@ -79,7 +125,10 @@ extern "C" int gns_forward(const gns_config* cfg, const void* topo_dev, const fl
   for (int k = 0; k < K; ++k) A.gw[k] = (float)std::pow((double)cfg->gamma, (double)(K - k));   // main.py:198
   A.Bt = Bt; A.G = L.groups; A.N = N; A.E = E; A.K = K; A.save = save_state ? 1 : 0; A.zero = 0;
   A.part_idx = gns_part_index(GNS_FWD_THREADS / 64);
-  return gns_launch_forward(d, h, cfg->multiple_phi, A, GNS_FWD_THREADS, st);
+  prof_mark(0, true, st);
+  rc = gns_launch_forward(d, h, cfg->multiple_phi, A, GNS_FWD_THREADS, st);
+  prof_mark(0, false, st);
+  return rc;
 }
 
 extern "C" int gns_backward(const gns_config* cfg, const void* topo_dev, const float* params, int64_t Bt,
@@ -117,7 +166,9 @@ extern "C" int gns_backward(const gns_config* cfg, const void* topo_dev, const f
   for (int k = 0; k < K; ++k) A.gw[k] = (float)std::pow((double)cfg->gamma, (double)(K - k));
   A.Bt = Bt; A.G = B.groups; A.slab_floats = B.slab_floats; A.N = N; A.E = E; A.K = K;
   A.part_idx = gns_part_index(GNS_BWD_WAVES);
+  prof_mark(1, true, st);
   rc = gns_launch_backward(d, h, cfg->multiple_phi, A, blocks, st);
+  prof_mark(1, false, st);
   if (rc != GNS_OK) return rc;
   return gns_launch_reduce(A.slab, (float*)(bw + B.off_part), grad_params, nslab, B.slab_floats, fam.flat_total, st);
 }

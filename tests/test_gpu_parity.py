@@ -51,3 +51,112 @@ def test_single_grid_2d_api_and_cpu_inputs(name):
     assert_close(v, g['v'][0], REL, what='v')
     assert_close(th, g['theta'][0], REL, what='theta')
     assert_close(tot, g['total_loss'][0], REL, what='total')
+
+
+@pytest.mark.parametrize('name', golden_names())
+def test_parameter_gradient_matches_reference_autograd(name):
+    """d(mean total_loss)/d(params) against the reference's own .backward() (GNS/main.py:284-288).
+    Gradient tolerance 5e-5 of max|grad| (fp32 products of ~1e5 terms summed in a different order)."""
+    g = load_golden(name)
+    m = _model(g)
+    v, th, tot, last = m(t(g['buses']).cuda(), t(g['lines']).cuda(), t(g['generators']).cuda())
+    tot.mean().backward()
+    grad = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).cpu().numpy()
+    assert_close(grad, g['grad_params'], 5e-5, abs_floor=1e-7, what='grad_params')
+    none = set(str(s) for s in g['none_grad_names'])       # L_m.{K-1}, phi_m.{K-1}: no gradient in the reference
+    for n, p in m.named_parameters():
+        if n in none:
+            assert float(p.grad.abs().max()) == 0.0, n
+
+
+def test_full_size_batch_against_oracle_sample_and_properties():
+    """BASELINE config 2/3 scale: case30 batch 4096 and case118 batch 16384 through the fused path.
+    Checked (a) against the CPU oracle on a sample of grids, (b) bitwise run-to-run reproducibility,
+    (c) batch-composition independence: a grid's outputs do not depend on its neighbours in the batch,
+    (d) the batch gradient is the mean of shard gradients (the identity data parallelism relies on)."""
+    import opf_graph_neural_solver_amd as amd
+    from oracle import gns_oracle as orc
+    for case, bt in ((30, 4096), (118, 16384)):
+        torch.manual_seed(1)
+        m = amd.GNS(20, 10, 4, 0.9, True).cuda()
+        bu, li, ge = amd.synth.synth_grids(case, bt, seed=5, device='cuda')
+        v, th, tot, last = m(bu, li, ge)
+        tot.mean().backward()
+        g_all = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
+        flat = m.flat_parameters().detach().cpu()
+        params = orc.unflatten_params(flat, 20, 10, 4, True)
+        for b in (0, 1, 63, 64, bt // 2 + 7, bt - 1):
+            vo, tho, toto, lasto = orc.gns_forward(params, bu[b].cpu(), li[b].cpu(), ge[b].cpu(), latent_dim=20, K=4,
+                                                  gamma=0.9, multiple_phi=True)
+            assert_close(v[b].detach().cpu(), vo, REL, what=f'v[{b}]')
+            assert_close(th[b].detach().cpu(), tho, REL, what=f'theta[{b}]')
+            assert_close(tot[b].detach().cpu(), toto, REL, what=f'total[{b}]')
+        # (b) bitwise reproducibility (no atomics anywhere)
+        m.zero_grad()
+        v2, th2, tot2, _ = m(bu, li, ge)
+        tot2.mean().backward()
+        g_again = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+        assert torch.equal(v, v2) and torch.equal(th, th2) and torch.equal(tot, tot2) and torch.equal(g_all, g_again)
+        # (c) a slice of the batch, alone, gives bitwise the same per-grid outputs
+        with torch.no_grad():
+            vs, ths, tots, _ = m(bu[100:229], li[100:229], ge[100:229])
+        assert torch.equal(vs, v[100:229]) and torch.equal(ths, th[100:229]) and torch.equal(tots, tot[100:229])
+        # (d) mean of two half-batch gradients == full-batch gradient
+        halves = []
+        for lo, hi in ((0, bt // 2), (bt // 2, bt)):
+            m.zero_grad()
+            _, _, t_h, _ = m(bu[lo:hi], li[lo:hi], ge[lo:hi])
+            t_h.mean().backward()
+            halves.append(torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone())
+        assert_close((0.5 * (halves[0] + halves[1])).cpu(), g_all.cpu(), 2e-5, abs_floor=1e-7, what='half-batch mean')
+
+
+def test_ragged_batches_and_upstream_gradients():
+    """Batch sizes that do not fill a 64-grid wave (1, 63, 65, 130) and gradients flowing in through v, theta and
+    last_loss - checked against autograd on the CPU oracle."""
+    import opf_graph_neural_solver_amd as amd
+    from oracle import gns_oracle as orc
+    torch.manual_seed(7)
+    m = amd.GNS(10, 10, 3, 0.9, False).cuda()
+    flat = m.flat_parameters().detach().cpu()
+    for bt in (1, 63, 65, 130):
+        bu, li, ge = amd.synth.synth_grids(14, bt, seed=bt)
+        wv, wth = torch.randn(bt, 14), torch.randn(bt, 14)
+        m.zero_grad()
+        v, th, tot, last = m(bu.cuda(), li.cuda(), ge.cuda())
+        loss = (v * wv.cuda()).sum() + (th * wth.cuda()).sum() + 0.3 * tot.sum() + 0.7 * last.sum()
+        loss.backward()
+        grad = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).cpu()
+        fo = flat.clone().requires_grad_(True)
+        po = orc.unflatten_params(fo, 10, 10, 3, False)
+        acc = 0.
+        for b in range(bt):
+            vo, tho, toto, lasto = orc.gns_forward(po, bu[b], li[b], ge[b], latent_dim=10, K=3, gamma=0.9, multiple_phi=False)
+            acc = acc + (vo * wv[b]).sum() + (tho * wth[b]).sum() + 0.3 * toto + 0.7 * lasto
+            assert_close(v[b].detach().cpu(), vo.detach(), REL, what='v')
+        acc.backward()
+        assert_close(grad, fo.grad, 5e-5, abs_floor=1e-6, what=f'grad bt={bt}')
+
+
+def test_error_behaviour_on_device():
+    import opf_graph_neural_solver_amd as amd
+    m = amd.GNS(20, 10, 2, 0.9, True).cuda()
+    bu, li, ge = amd.synth.synth_grids(14, 4, seed=0, device='cuda')
+    bad = li.clone(); bad[2, 3, 1] = 5.0          # one grid with a different t_bus
+    with pytest.raises(ValueError):
+        m(bu, bad, ge)
+    bad = li.clone(); bad[:, 0, 0] = 99.0         # bus id out of range
+    with pytest.raises(ValueError):
+        m(bu, bad, ge)
+    with pytest.raises(ValueError):
+        m(bu.double(), li, ge)
+    cpu_model = amd.GNS(20, 10, 2, 0.9, True)
+    with pytest.raises(amd.GNSError):
+        cpu_model(bu.cpu(), li.cpu(), ge.cpu())     # no CPU fallback
+    with pytest.raises(amd.GNSError):
+        amd.GNS(12, 10, 2, 0.9, True).cuda()(bu, li, ge)   # no kernel compiled for latent_dim 12
+
+
+def test_smoke_entry():
+    import __graft_entry__ as ge
+    ge.smoke()
