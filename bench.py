@@ -62,7 +62,8 @@ def cpu_baseline(seconds=14.0):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))
+    # The GPU box's process guard allows 6 processes with the device open and `import torch` opens it: 5 workers + this one.
+    cores = max(1, min(cores, 5))
     ctx = mp.get_context('spawn')     # fresh interpreters; the parent has not touched the GPU yet
     with ctx.Pool(cores) as pool:
         res = pool.map(_cpu_worker, [(seconds, i) for i in range(cores)])
