@@ -17,7 +17,8 @@ class GnsConfig(ctypes.Structure):
 
 
 def library_path():
-    return os.path.join(_HERE, 'libgns_hip.so')
+    # GNS_LIB selects an alternative build (ablation / A-B timing runs); the default is the shipped library
+    return os.environ.get('GNS_LIB') or os.path.join(_HERE, 'libgns_hip.so')
 
 
 def load_library():

@@ -2,6 +2,7 @@
 // kernels on the caller's stream.  No allocation, no synchronisation, no host<->device copies.
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include "gns_kernels.h"
 
 static bool dims_supported(int d, int h) {
@@ -124,9 +125,11 @@ extern "C" int gns_forward(const gns_config* cfg, const void* topo_dev, const fl
   for (int i = 0; i < fam.nfam; ++i) { A.t_off[i] = fam.t_off[i]; A.t_sz[i] = fam.t_sz[i]; }
   for (int k = 0; k < K; ++k) A.gw[k] = (float)std::pow((double)cfg->gamma, (double)(K - k));   // main.py:198
   A.Bt = Bt; A.G = L.groups; A.N = N; A.E = E; A.K = K; A.save = save_state ? 1 : 0; A.zero = 0;
-  A.part_idx = gns_part_index(GNS_FWD_THREADS / 64);
+  int waves = GNS_FWD_THREADS / 64;
+  if (const char* e = std::getenv("GNS_FWD_WAVES")) { int w = std::atoi(e); if (gns_part_index(w) >= 0 && w * 64 <= GNS_FWD_MAX_THREADS) waves = w; }
+  A.part_idx = gns_part_index(waves);
   prof_mark(0, true, st);
-  rc = gns_launch_forward(d, h, cfg->multiple_phi, A, GNS_FWD_THREADS, st);
+  rc = gns_launch_forward(d, h, cfg->multiple_phi, A, waves * 64, st);
   prof_mark(0, false, st);
   return rc;
 }

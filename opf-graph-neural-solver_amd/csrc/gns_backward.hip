@@ -34,7 +34,7 @@ template <int N, int I>
 __device__ __forceinline__ float pick(const float (&x)[N]) { return x[I]; }
 
 template <int IN, int H, int OUT, int OUTP>
-__device__ __forceinline__ void rec_write(float* rec, int row, const float (&x)[IN], const f2 (&a1)[H / 2], const f2 (&a2)[H / 2],
+__device__ __forceinline__ void rec_write(float* rec, int row, const f2 (&x)[(IN + 1) / 2], const f2 (&a1)[H / 2], const f2 (&a2)[H / 2],
                                           const f2 (&g1)[H / 2], const f2 (&g2)[H / 2], const f2 (&g3)[OUTP / 2]) {
   using R = RecLay<IN, H, OUT>;
   f4* dst = reinterpret_cast<f4*>(rec + row * R::RS);
@@ -45,7 +45,7 @@ __device__ __forceinline__ void rec_write(float* rec, int row, const float (&x)[
       constexpr int c = decltype(c_)::value;
       constexpr int o = 4 * q + c;
       if constexpr (o < R::oA1) {
-        if constexpr (o < IN) e[c] = x[o]; else e[c] = (o == IN) ? 1.f : 0.f;
+        if constexpr (o < IN) e[c] = lane_of<o>(x); else e[c] = (o == IN) ? 1.f : 0.f;
       } else if constexpr (o < R::oA2) {
         constexpr int i = o - R::oA1;
         if constexpr (i < H) e[c] = lane_of<i>(a1); else e[c] = (i == H) ? 1.f : 0.f;
@@ -67,31 +67,40 @@ __device__ __forceinline__ void rec_write(float* rec, int row, const float (&x)[
   });
 }
 
-// Weight gradient of one LearningBlock for the 64 grids of this wave (dW += sum_grids g (x) input), flat layout
-// W1[H][IN] b1[H] W2[H][H] b2[H] W4[OUT][H] b4[OUT] at slab_blk.  Lane t < NT owns the 4x4 tile t.
-template <int IN, int H, int OUT, int OUTP>
-__device__ __forceinline__ void dw_net(float* rec, int lane, float* slab_blk, const float (&x)[IN], const f2 (&a1)[H / 2],
-                                       const f2 (&a2)[H / 2], const f2 (&g1)[H / 2], const f2 (&g2)[H / 2],
-                                       const f2 (&g3)[OUTP / 2]) {
+// Weight gradient of one LearningBlock for the 64 grids of this wave: dW += sum_grids g (x) input.
+// Lane t < NT owns the 4x4 tile t of [dW1|db1], [dW2|db2] or [dW4|db4]; the tile lives in registers across all
+// the rows (buses / lines) a wave handles in one reverse step and is flushed once, into the wave's slab in the
+// flat layout W1[H][IN] b1[H] W2[H][H] b2[H] W4[OUT][H] b4[OUT].
+struct DwTile { int kind, cb, ib, woff, uoff; };
+
+template <int IN, int H, int OUT>
+__device__ __forceinline__ DwTile dw_tile(int lane) {
   using R = RecLay<IN, H, OUT>;
-  int kind, cb, ib, woff, uoff;
-  {
-    int t = lane < R::NT ? lane : 0;
-    if (t < R::T1) { kind = 0; cb = t / R::TX; ib = t % R::TX; woff = R::oG1 + 4 * cb; uoff = R::oX + 4 * ib; }
-    else if (t < R::T1 + R::T2) { t -= R::T1; kind = 1; cb = t / R::TH; ib = t % R::TH; woff = R::oG2 + 4 * cb; uoff = R::oA1 + 4 * ib; }
-    else { t -= R::T1 + R::T2; kind = 2; cb = t / R::TH; ib = t % R::TH; woff = R::oG3 + 4 * cb; uoff = R::oA2 + 4 * ib; }
-  }
-  f2 acc[4][2];
-#pragma unroll
-  for (int a = 0; a < 4; ++a) { acc[a][0] = f2{0.f, 0.f}; acc[a][1] = f2{0.f, 0.f}; }
+  DwTile T;
+  int t = lane < R::NT ? lane : 0;
+  if (t < R::T1) { T.kind = 0; T.cb = t / R::TX; T.ib = t % R::TX; T.woff = R::oG1 + 4 * T.cb; T.uoff = R::oX + 4 * T.ib; }
+  else if (t < R::T1 + R::T2) { t -= R::T1; T.kind = 1; T.cb = t / R::TH; T.ib = t % R::TH; T.woff = R::oG2 + 4 * T.cb; T.uoff = R::oA1 + 4 * T.ib; }
+  else { t -= R::T1 + R::T2; T.kind = 2; T.cb = t / R::TH; T.ib = t % R::TH; T.woff = R::oG3 + 4 * T.cb; T.uoff = R::oA2 + 4 * T.ib; }
+  return T;
+}
+
+template <int IN, int H, int OUT, int OUTP>
+__device__ __forceinline__ void dw_accumulate(float* rec, int lane, const DwTile& T, f2 (&acc)[4][2], const f2 (&x)[(IN + 1) / 2],
+                                              const f2 (&a1)[H / 2], const f2 (&a2)[H / 2], const f2 (&g1)[H / 2],
+                                              const f2 (&g2)[H / 2], const f2 (&g3)[OUTP / 2]) {
+  using R = RecLay<IN, H, OUT>;
+#ifdef GNS_ABLATE_DW
+  asm volatile("" :: "v"(x[0]), "v"(a1[0]), "v"(a2[0]), "v"(g1[0]), "v"(g2[0]), "v"(g3[0]));
+  return;
+#endif
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     if ((lane >> 5) == half) rec_write<IN, H, OUT, OUTP>(rec, lane & 31, x, a1, a2, g1, g2, g3);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const float* rw = rec + woff;
-    const float* ru = rec + uoff;
-#pragma unroll 8
+    const float* rw = rec + T.woff;
+    const float* ru = rec + T.uoff;
+#pragma unroll 4
     for (int r = 0; r < GNS_REC_ROWS; ++r) {
       const f4 w = *reinterpret_cast<const f4*>(rw + r * R::RS);
       const f4 u = *reinterpret_cast<const f4*>(ru + r * R::RS);
@@ -104,23 +113,33 @@ __device__ __forceinline__ void dw_net(float* rec, int lane, float* slab_blk, co
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
+}
+
+template <int IN, int H, int OUT>
+__device__ __forceinline__ void dw_flush(int lane, const DwTile& T, const f2 (&acc)[4][2], float* slab_blk) {
+  using R = RecLay<IN, H, OUT>;
   if (lane < R::NT) {
     constexpr int ob1 = IN * H, oW2 = ob1 + H, ob2 = oW2 + H * H, oW4 = ob2 + H, ob4 = oW4 + OUT * H;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-      const int c = 4 * cb + a;
+      const int c = 4 * T.cb + a;
 #pragma unroll
       for (int bq = 0; bq < 4; ++bq) {
-        const int i = 4 * ib + bq;
+        const int i = 4 * T.ib + bq;
         const float val = (bq & 1) ? acc[a][bq >> 1].y : acc[a][bq >> 1].x;
         int idx = -1;
-        if (kind == 0) { if (c < H) idx = (i < IN) ? c * IN + i : (i == IN ? ob1 + c : -1); }
-        else if (kind == 1) { if (c < H) idx = (i < H) ? oW2 + c * H + i : (i == H ? ob2 + c : -1); }
+        if (T.kind == 0) { if (c < H) idx = (i < IN) ? c * IN + i : (i == IN ? ob1 + c : -1); }
+        else if (T.kind == 1) { if (c < H) idx = (i < H) ? oW2 + c * H + i : (i == H ? ob2 + c : -1); }
         else { if (c < OUT) idx = (i < H) ? oW4 + c * H + i : (i == H ? ob4 + c : -1); }
         if (idx >= 0) slab_blk[idx] += val;
       }
     }
   }
+}
+
+__device__ __forceinline__ void zero_acc(f2 (&acc)[4][2]) {
+#pragma unroll
+  for (int a = 0; a < 4; ++a) { acc[a][0] = f2{0.f, 0.f}; acc[a][1] = f2{0.f, 0.f}; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -161,7 +180,8 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
     const float gt = (live && A.g_total) ? A.g_total[b] : 0.f;
     const float gl = (live && A.g_last) ? A.g_last[b] : 0.f;
     auto state_row = [&](int slot, int n) { return (((long long)slot * A.G + g) * N + n) * RB; };
-    auto adj_row = [&](int n) { return (g * N + n) * RB; };
+    constexpr int RBA = RB + 1;      // (vbar, thbar, dpbar, -) | input-adjoint sums of this step | mbar
+    auto adj_row = [&](int n) { return (g * N + n) * RBA; };
     auto slot_ptr = [&](int j, int p) { return A.slots + ((g * 6 + j) * E + p) * GNS_LANES + lane; };
     const f4 gsum = *row_ptr(IN, row_grid, lane);
 
@@ -173,7 +193,7 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
       const long long ar = adj_row(n);
       *row_ptr(A.adj, ar, lane) = f4{vb, tb, 0.f, 0.f};
 #pragma unroll
-      for (int q = 0; q < C::MQ; ++q) *row_ptr(A.adj, ar + 1 + q, lane) = f4{0.f, 0.f, 0.f, 0.f};
+      for (int q = 0; q < 1 + C::MQ; ++q) *row_ptr(A.adj, ar + 1 + q, lane) = f4{0.f, 0.f, 0.f, 0.f};
     }
 
     for (int k = K - 1; k >= 0; --k) {
@@ -244,14 +264,12 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
       }
       __syncthreads();
 
-      // ---------------- Ub ----------------
+      // ---------------- Ub, pass G: every bus completes d/d(v,theta)_{k+1} from the per-line adjoints --------------
       for (int n = n0; n < n1; ++n) {
         const long long ar = adj_row(n);
         const f4 a0 = *row_ptr(A.adj, ar, lane);
         float vbar = a0.x, thbar = a0.y;
         const float dpb = a0.z;
-        float mbar[D];
-        load_vec<D>(A.adj, ar + 1, lane, mbar);
         const int p0 = in_ptr[n], p1 = in_ptr[n + 1];
         for (int p = p0; p < p1; ++p) { vbar += *slot_ptr(1, p); thbar += *slot_ptr(3, p); }
         const int q0 = out_ptr[n], q1 = out_ptr[n + 1];
@@ -262,93 +280,124 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
           const float val = *slot_ptr((code & 2) ? 5 : 4, code >> 2);
           thbar += (code & 1) ? -val : val;
         }
-        {
-          const f4 s1 = *row_ptr(A.state, state_row(k + 1, n), lane);
-          const float Gs = row_ptr(IN, in_base + 3LL * n, lane)->z;
-          vbar += (pgbar - dpb) * (2.f * Gs * s1.x);     // -Gs v^2 in dp (main.py:82) and +Gs v^2 in p_global (main.py:45)
-        }
-        // recompute the update step k of this bus (main.py:155-188)
-        const long long rr = state_row(k, n);
-        const f4 s0 = *row_ptr(A.state, rr, lane);
-        float m[D];
-        load_vec<D>(A.state, rr + 1, lane, m);
-        f2 S[C::NPHI][C::PHI_OUTP / 2];
+        const f4 s1 = *row_ptr(A.state, state_row(k + 1, n), lane);
+        const float Gs = row_ptr(IN, in_base + 3LL * n, lane)->z;
+        vbar += (pgbar - dpb) * (2.f * Gs * s1.x);     // -Gs v^2 in dp (main.py:82) and +Gs v^2 in p_global (main.py:45)
+        *row_ptr(A.adj, ar, lane) = f4{vbar, thbar, dpb, 0.f};
+      }
+
+      // ---------------- Ub, one pass over the buses per network family (main.py:155-188 recomputed + reversed) ------
+      // Family-outer order keeps the 4x4 weight-gradient tiles of (L_l, phi_f) in registers for the whole pass.
+      auto edge_input = [&](int p, const f2 (&m)[D / 2], f2 (&x)[(C::PHI_IN + 1) / 2]) {
+        const f4 ea = *row_ptr(IN, row_ein + 3LL * p, lane), eb = *row_ptr(IN, row_ein + 3LL * p + 1, lane);
 #pragma unroll
-        for (int f = 0; f < C::NPHI; ++f)
+        for (int i = 0; i < D / 2; ++i) x[i] = m[i];
+        x[D / 2] = f2{ea.x, ea.y}; x[D / 2 + 1] = f2{ea.z, ea.w}; x[D / 2 + 2] = f2{eb.x, 0.f};
+      };
+      static_for<0, 3>([&](auto o_) {
+        constexpr int l = (decltype(o_)::value == 0) ? 2 : decltype(o_)::value - 1;   // L_m first: its upstream is mbar_{k+1} itself
+        constexpr int fphi = MULTI ? (l == 0 ? 1 : (l == 1 ? 0 : 2)) : 0;
+        constexpr int OUT = (l == 2) ? D : 1, OUTP = OUT + (OUT & 1);
+        // after the last step nothing reads m_K: L_m.{K-1} / phi_m.{K-1} get no gradient (reference: .grad is None)
+        if (l == 2 && k == K - 1) return;
+        const DwTile TL = dw_tile<C::L_IN, H, OUT>(lane);
+        const DwTile TP = dw_tile<C::PHI_IN, H, C::PHI_OUT>(lane);
+        f2 accL[4][2], accP[4][2];
+        zero_acc(accL); zero_acc(accP);
+        for (int n = n0; n < n1; ++n) {
+          const long long ar = adj_row(n), rr = state_row(k, n);
+          const f4 a0 = *row_ptr(A.adj, ar, lane);
+          f4 xsum = *row_ptr(A.adj, ar + 1, lane);            // (d/dv, d/dtheta, d/ddp of the L inputs so far, gS of the single phi)
+          const f4 s0 = *row_ptr(A.state, rr, lane);
+          f2 m[D / 2];
+          load_pairs<D>(A.state, rr + 1, lane, m);
+          // gx is the adjoint of the L-net input [v theta | dp dq | m | message sum]; its m part starts as d/dm_{k+1}
+          // (identity path main.py:188) and keeps accumulating, so no separate copy of the latent adjoint is live
+          f2 gx[C::L_IN / 2];
+          f2 (&macc)[D / 2] = reinterpret_cast<f2 (&)[D / 2]>(gx[2]);
+          f2 (&gS)[D / 2] = reinterpret_cast<f2 (&)[D / 2]>(gx[2 + D / 2]);
+          gx[0] = f2{0.f, 0.f}; gx[1] = f2{0.f, 0.f};
+          load_pairs<D>(A.adj, ar + 2, lane, macc);
 #pragma unroll
-          for (int j = 0; j < C::PHI_OUTP / 2; ++j) S[f][j] = f2{0.f, 0.f};
-        for (int p = p0; p < p1; ++p) {
-          const f4 ea = *row_ptr(IN, row_ein + 3LL * p, lane), eb = *row_ptr(IN, row_ein + 3LL * p + 1, lane);
-          float x[C::PHI_IN];
+          for (int j = 0; j < D / 2; ++j) gS[j] = f2{0.f, 0.f};
+          const int p0 = in_ptr[n], p1 = in_ptr[n + 1];
+          {
+            f2 x[C::L_IN / 2];
+            f2 (&S)[D / 2] = reinterpret_cast<f2 (&)[D / 2]>(x[2 + D / 2]);
 #pragma unroll
-          for (int i = 0; i < D; ++i) x[i] = m[i];
-          x[D] = ea.x; x[D + 1] = ea.y; x[D + 2] = ea.z; x[D + 3] = ea.w; x[D + 4] = eb.x;
-          static_for<0, C::NPHI>([&](auto f_) {
-            constexpr int f = decltype(f_)::value;
-            f2 a1[H / 2], a2[H / 2], y[C::PHI_OUTP / 2];
-            mlp_fwd<C::PHI_IN, H, C::PHI_OUTP>(PT + A.t_off[f] + koff * A.t_sz[f], x, a1, a2, y);
+            for (int j = 0; j < D / 2; ++j) S[j] = f2{0.f, 0.f};
+            for (int p = p0; p < p1; ++p) {                     // message sum of family fphi (main.py:155-163)
+              f2 xe[(C::PHI_IN + 1) / 2], a1[H / 2], a2[H / 2], y[C::PHI_OUTP / 2];
+              edge_input(p, m, xe);
+              mlp_fwd<C::PHI_IN, H, C::PHI_OUTP>(PT + A.t_off[fphi] + koff * A.t_sz[fphi], xe, a1, a2, y);
+              if constexpr (MULTI) {
 #pragma unroll
-            for (int j = 0; j < C::PHI_OUTP / 2; ++j) S[f][j] += y[j];
-          });
-        }
-        constexpr int HEAD = (4 + D) / 2;            // pairs of [v theta dp dq | m]
-        f2 xs[HEAD];
+                for (int j = 0; j < D / 2; ++j) S[j] += y[j];
+              } else {
+                S[0].x += y[0].x;                               // [E,1] scattered into column 0 (main.py:170)
+              }
+            }
+            x[0] = f2{s0.x, s0.y}; x[1] = f2{s0.z, s0.w};
 #pragma unroll
-        for (int j = 0; j < HEAD; ++j) xs[j] = f2{0.f, 0.f};
-        f2 gS[C::NPHI][C::PHI_OUTP / 2];
+            for (int i = 0; i < D / 2; ++i) x[2 + i] = m[i];
+            f2 a1[H / 2], a2[H / 2], y[OUTP / 2], g3[OUTP / 2], g2[H / 2], g1[H / 2];
+            mlp_fwd<C::L_IN, H, OUTP>(PT + A.t_off[C::NPHI + l] + koff * A.t_sz[C::NPHI + l], x, a1, a2, y);
+            if constexpr (l == 0) g3[0] = f2{a0.y, 0.f};                                  // theta += L_theta (main.py:182)
+            else if constexpr (l == 1) g3[0] = f2{is_gen[n] ? 0.f : a0.x, 0.f};           // v moves only without a generator (main.py:184-186)
+            else {
 #pragma unroll
-        for (int f = 0; f < C::NPHI; ++f)
-#pragma unroll
-          for (int j = 0; j < C::PHI_OUTP / 2; ++j) gS[f][j] = f2{0.f, 0.f};
-        const float vgate = is_gen[n] ? 0.f : vbar;   // v only moves on buses without a generator (main.py:184-186)
-        static_for<0, 3>([&](auto l_) {
-          constexpr int l = decltype(l_)::value;
-          constexpr int fphi = MULTI ? (l == 0 ? 1 : (l == 1 ? 0 : 2)) : 0;
-          constexpr int OUT = (l == 2) ? D : 1, OUTP = OUT + (OUT & 1);
-          float x[C::L_IN];
-          x[0] = s0.x; x[1] = s0.y; x[2] = s0.z; x[3] = s0.w;
-#pragma unroll
-          for (int i = 0; i < D; ++i) x[4 + i] = m[i];
-          static_for<0, D>([&](auto i_) {
-            constexpr int i = decltype(i_)::value;
-            if constexpr (MULTI) x[4 + D + i] = lane_of<i>(S[fphi]);
-            else x[4 + D + i] = (i == 0) ? S[0][0].x : 0.f;
-          });
-          f2 a1[H / 2], a2[H / 2], y[OUTP / 2], g3[OUTP / 2], g2[H / 2], g1[H / 2], gx[C::L_IN / 2];
-          mlp_fwd<C::L_IN, H, OUTP>(PT + A.t_off[C::NPHI + l] + koff * A.t_sz[C::NPHI + l], x, a1, a2, y);
-          if constexpr (l == 0) g3[0] = f2{thbar, 0.f};
-          else if constexpr (l == 1) g3[0] = f2{vgate, 0.f};
-          else static_for<0, D / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; g3[j] = f2{mbar[2 * j], mbar[2 * j + 1]}; });
-          mlp_bwd<C::L_IN, H, OUTP, C::L_IN>(PN + A.n_off[C::NPHI + l] + koff * A.n_sz[C::NPHI + l], a1, a2, g3, g2, g1, gx);
-#pragma unroll
-          for (int j = 0; j < HEAD; ++j) xs[j] += gx[j];
-          if constexpr (MULTI) {
-#pragma unroll
-            for (int j = 0; j < D / 2; ++j) gS[fphi][j] = gx[HEAD + j];
-          } else {
-            gS[0][0].x += gx[HEAD].x;
+              for (int j = 0; j < D / 2; ++j) g3[j] = macc[j];                            // m += L_m (main.py:188)
+            }
+            mlp_bwd<C::L_IN, H, OUTP, C::L_IN, true>(PN + A.n_off[C::NPHI + l] + koff * A.n_sz[C::NPHI + l], a1, a2, g3, g2, g1, gx);
+            xsum.x += gx[0].x; xsum.y += gx[0].y; xsum.z += gx[1].x;
+            if constexpr (!MULTI) xsum.w += gS[0].x;            // all three L nets read column 0 of the same message sum
+            dw_accumulate<C::L_IN, H, OUT, OUTP>(rec, lane, TL, accL, x, a1, a2, g1, g2, g3);
           }
-          dw_net<C::L_IN, H, OUT, OUTP>(rec, lane, slab + A.f_off[C::NPHI + l] + koff * A.f_sz[C::NPHI + l], x, a1, a2, g1, g2, g3);
-        });
-        float mnew[D];
-        static_for<0, D>([&](auto i_) { constexpr int i = decltype(i_)::value; mnew[i] = mbar[i] + lane_of<4 + i>(xs); });
-        for (int p = p0; p < p1; ++p) {                  // back through the messages of the lines ending at n
-          const f4 ea = *row_ptr(IN, row_ein + 3LL * p, lane), eb = *row_ptr(IN, row_ein + 3LL * p + 1, lane);
-          float x[C::PHI_IN];
-#pragma unroll
-          for (int i = 0; i < D; ++i) x[i] = m[i];
-          x[D] = ea.x; x[D + 1] = ea.y; x[D + 2] = ea.z; x[D + 3] = ea.w; x[D + 4] = eb.x;
-          static_for<0, C::NPHI>([&](auto f_) {
-            constexpr int f = decltype(f_)::value;
-            f2 a1[H / 2], a2[H / 2], y[C::PHI_OUTP / 2], g2[H / 2], g1[H / 2], gx[D / 2];
-            mlp_fwd<C::PHI_IN, H, C::PHI_OUTP>(PT + A.t_off[f] + koff * A.t_sz[f], x, a1, a2, y);
-            mlp_bwd<C::PHI_IN, H, C::PHI_OUTP, D>(PN + A.n_off[f] + koff * A.n_sz[f], a1, a2, gS[f], g2, g1, gx);
-            static_for<0, D>([&](auto i_) { constexpr int i = decltype(i_)::value; mnew[i] += lane_of<i>(gx); });
-            dw_net<C::PHI_IN, H, C::PHI_OUT, C::PHI_OUTP>(rec, lane, slab + A.f_off[f] + koff * A.f_sz[f], x, a1, a2, g1, g2, gS[f]);
-          });
+          if constexpr (MULTI) {
+            for (int p = p0; p < p1; ++p) {                     // back through the messages of the lines ending at n
+              f2 xe[(C::PHI_IN + 1) / 2], a1[H / 2], a2[H / 2], y[C::PHI_OUTP / 2], g2[H / 2], g1[H / 2];
+              edge_input(p, m, xe);
+              mlp_fwd<C::PHI_IN, H, C::PHI_OUTP>(PT + A.t_off[fphi] + koff * A.t_sz[fphi], xe, a1, a2, y);
+              // x = [m(dst) | ...] (main.py:155): the m part of the input adjoint goes straight into macc
+              mlp_bwd<C::PHI_IN, H, C::PHI_OUTP, D, true>(PN + A.n_off[fphi] + koff * A.n_sz[fphi], a1, a2, gS, g2, g1, macc);
+              dw_accumulate<C::PHI_IN, H, C::PHI_OUT, C::PHI_OUTP>(rec, lane, TP, accP, xe, a1, a2, g1, g2, gS);
+            }
+          }
+          *row_ptr(A.adj, ar + 1, lane) = xsum;
+          store_pairs<D>(A.adj, ar + 2, lane, macc);
         }
-        *row_ptr(A.adj, ar, lane) = f4{vbar + xs[0].x, thbar + xs[0].y, xs[1].x, 0.f};   // main.py:182,186 identity paths
-        store_vec<D>(A.adj, ar + 1, lane, mnew);
+        dw_flush<C::L_IN, H, OUT>(lane, TL, accL, slab + A.f_off[C::NPHI + l] + koff * A.f_sz[C::NPHI + l]);
+        if constexpr (MULTI) dw_flush<C::PHI_IN, H, C::PHI_OUT>(lane, TP, accP, slab + A.f_off[fphi] + koff * A.f_sz[fphi]);
+      });
+      if constexpr (!MULTI) {                                  // the single phi: its output adjoint is the sum over the three L nets
+        const DwTile TP = dw_tile<C::PHI_IN, H, C::PHI_OUT>(lane);
+        f2 accP[4][2];
+        zero_acc(accP);
+        for (int n = n0; n < n1; ++n) {
+          const long long ar = adj_row(n), rr = state_row(k, n);
+          const f4 xsum = *row_ptr(A.adj, ar + 1, lane);
+          f2 m[D / 2], macc[D / 2], gS[1];
+          load_pairs<D>(A.state, rr + 1, lane, m);
+          load_pairs<D>(A.adj, ar + 2, lane, macc);
+          gS[0] = f2{xsum.w, 0.f};
+          const int p0 = in_ptr[n], p1 = in_ptr[n + 1];
+          for (int p = p0; p < p1; ++p) {
+            f2 x[(C::PHI_IN + 1) / 2], a1[H / 2], a2[H / 2], y[1], g2[H / 2], g1[H / 2];
+            edge_input(p, m, x);
+            mlp_fwd<C::PHI_IN, H, 2>(PT + A.t_off[0] + koff * A.t_sz[0], x, a1, a2, y);
+            mlp_bwd<C::PHI_IN, H, 2, D, true>(PN + A.n_off[0] + koff * A.n_sz[0], a1, a2, gS, g2, g1, macc);
+            dw_accumulate<C::PHI_IN, H, 1, 2>(rec, lane, TP, accP, x, a1, a2, g1, g2, gS);
+          }
+          store_pairs<D>(A.adj, ar + 2, lane, macc);
+        }
+        dw_flush<C::PHI_IN, H, 1>(lane, TP, accP, slab + A.f_off[0] + koff * A.f_sz[0]);
+      }
+      // ---------------- finalize: (vbar, thbar)_k = identity path + input adjoints; dpbar_k for the next Pb-0 -----------
+      for (int n = n0; n < n1; ++n) {
+        const long long ar = adj_row(n);
+        const f4 a0 = *row_ptr(A.adj, ar, lane), xsum = *row_ptr(A.adj, ar + 1, lane);
+        *row_ptr(A.adj, ar, lane) = f4{a0.x + xsum.x, a0.y + xsum.y, xsum.z, 0.f};     // main.py:182,186 identity paths
+        *row_ptr(A.adj, ar + 1, lane) = f4{0.f, 0.f, 0.f, 0.f};
       }
     }
     __syncthreads();

@@ -138,7 +138,7 @@ static inline void gns_bwd_layout(int N, int E, int d, int h, int K, int multi, 
   int64_t wg = B->groups < GNS_BWD_MAX_WG ? B->groups : GNS_BWD_MAX_WG;
   B->nslab = wg * GNS_BWD_WAVES;
   size_t o = 0;
-  B->off_adj = o;   o = gns_align256(o + (size_t)B->groups * N * B->rows_bus * GNS_LANES * 16);   // (vbar,thbar,dpbar,-) + mbar
+  B->off_adj = o;   o = gns_align256(o + (size_t)B->groups * N * (B->rows_bus + 1) * GNS_LANES * 16);   // (vbar,thbar,dpbar,-) | input adjoints | mbar
   B->off_slots = o; o = gns_align256(o + (size_t)B->groups * 6 * E * GNS_LANES * 4);               // 6 adjoint planes per line
   B->off_slab = o;  o = gns_align256(o + (size_t)B->nslab * B->slab_floats * 4);
   B->off_part = o;  o = gns_align256(o + (size_t)GNS_RED_PARTS * B->slab_floats * 4);

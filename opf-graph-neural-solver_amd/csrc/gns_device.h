@@ -37,14 +37,13 @@ __device__ __forceinline__ int opaque_zero() {
 template <int NF, class F>
 __device__ __forceinline__ void stream_pairs(cfp p, F&& f) {
   constexpr int NCH = (NF + 15) / 16;
-  p += opaque_zero();
   f16v bufA, bufB;
-  bufA = *(cf16p)(p);
+  bufA = *(cf16p)(p + opaque_zero());
   static_for<0, NCH>([&](auto c_) {
     constexpr int c = decltype(c_)::value;
     f16v& cur = (c & 1) ? bufB : bufA;
     f16v& nxt = (c & 1) ? bufA : bufB;
-    if constexpr (c + 1 < NCH) nxt = *(cf16p)(p + 16 * (c + 1));
+    if constexpr (c + 1 < NCH) nxt = *(cf16p)(p + 16 * (c + 1) + opaque_zero());   // a fresh opaque zero per chunk: IR passes cannot batch the loads
     __builtin_amdgcn_sched_barrier(0);
     static_for<0, 8>([&](auto t_) {
       constexpr int t = decltype(t_)::value;
@@ -53,6 +52,15 @@ __device__ __forceinline__ void stream_pairs(cfp p, F&& f) {
     });
     __builtin_amdgcn_sched_barrier(0);
   });
+}
+
+// Pin a value to the point where it was computed.  MachineSink otherwise moves a whole LearningBlock's FMAs down
+// to the first use of its result (past the next line loop), keeping ~600 weights alive in v_writelane spills.
+__device__ __forceinline__ void pin(f2& v) { asm volatile("" : "+v"(v)); }
+template <int N>
+__device__ __forceinline__ void pin_all(f2 (&a)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) pin(a[i]);
 }
 
 __device__ __forceinline__ f2 splat(float x) { return f2{x, x}; }
@@ -72,14 +80,15 @@ struct TLay {
 };
 
 template <int IN, int H, int OUTP>
-__device__ __forceinline__ void mlp_fwd(cfp blk, const float (&x)[IN], f2 (&a1)[H / 2], f2 (&a2)[H / 2], f2 (&y)[OUTP / 2]) {
+__device__ __forceinline__ void mlp_fwd(cfp blk, const f2 (&x)[(IN + 1) / 2], f2 (&a1)[H / 2], f2 (&a2)[H / 2], f2 (&y)[OUTP / 2]) {
   using B = TLay<IN, H, OUTP>;
   static_assert(H % 2 == 0 && OUTP % 2 == 0, "pairs");
   stream_pairs<B::total>(blk, [&](auto w_, f2 s) {
     constexpr int w = decltype(w_)::value;
     if constexpr (w < B::ob1) {
       constexpr int i = w / H, j = (w % H) / 2;
-      a1[j] = (i == 0) ? s * splat(x[0]) : __builtin_elementwise_fma(s, splat(x[i]), a1[j]);
+      const f2 xi = splat(lane_of<i>(x));        // inputs arrive as aligned pairs: op_sel picks the half, no v_mov
+      a1[j] = (i == 0) ? s * xi : __builtin_elementwise_fma(s, xi, a1[j]);
     } else if constexpr (w < B::oW2) {
       constexpr int j = (w - B::ob1) / 2;
       a1[j] = lrelu2(a1[j] + s);
@@ -99,6 +108,7 @@ __device__ __forceinline__ void mlp_fwd(cfp blk, const float (&x)[IN], f2 (&a1)[
       y[j] += s;
     }
   });
+  pin_all(y);
 }
 
 // LearningBlock backward, data path, from the N-stream: W4n[OUTP][H] W2n[H][H] W1n[H][INP]
@@ -109,7 +119,8 @@ struct NLay {
   static constexpr int oW4 = 0, oW2 = OUTP * H, oW1 = oW2 + H * H, total = oW1 + H * INP;
 };
 
-template <int IN, int H, int OUTP, int NX>
+// ACC = true: gx arrives holding values to accumulate into (e.g. the running adjoint of the latent vector).
+template <int IN, int H, int OUTP, int NX, bool ACC = false>
 __device__ __forceinline__ void mlp_bwd(cfp blk, const f2 (&a1)[H / 2], const f2 (&a2)[H / 2], const f2 (&g3)[OUTP / 2],
                                         f2 (&g2)[H / 2], f2 (&g1)[H / 2], f2 (&gx)[NX / 2]) {
   using B = NLay<IN, H, OUTP>;
@@ -134,10 +145,11 @@ __device__ __forceinline__ void mlp_bwd(cfp blk, const f2 (&a1)[H / 2], const f2
       }
       if constexpr (2 * i < NX) {
         const f2 gj = splat(lane_of<j>(g1));
-        gx[i] = (j == 0) ? s * gj : __builtin_elementwise_fma(s, gj, gx[i]);
+        gx[i] = (j == 0 && !ACC) ? s * gj : __builtin_elementwise_fma(s, gj, gx[i]);
       }
     }
   });
+  pin_all(gx);
 }
 
 // float4-row addressing: [row][lane] with 16 B per lane -> every wave access is one contiguous 1 KiB
@@ -148,7 +160,26 @@ __device__ __forceinline__ f4* row_ptr(float* base, long long row, int lane) {
   return reinterpret_cast<f4*>(base) + row * GNS_LANES + lane;
 }
 
-// D floats stored as ceil(D/4) consecutive float4 rows (unused tail components are written as 0)
+// D floats (D even) as pairs: ceil(D/4) consecutive float4 rows (unused tail components are written as 0)
+template <int D>
+__device__ __forceinline__ void load_pairs(const float* base, long long row, int lane, f2 (&m)[D / 2]) {
+  static_for<0, (D + 3) / 4>([&](auto q_) {
+    constexpr int q = decltype(q_)::value;
+    const f4 t = *row_ptr(base, row + q, lane);
+    m[2 * q] = f2{t.x, t.y};
+    if constexpr (2 * q + 1 < D / 2) m[2 * q + 1] = f2{t.z, t.w};
+  });
+}
+template <int D>
+__device__ __forceinline__ void store_pairs(float* base, long long row, int lane, const f2 (&m)[D / 2]) {
+  static_for<0, (D + 3) / 4>([&](auto q_) {
+    constexpr int q = decltype(q_)::value;
+    f4 t = {m[2 * q].x, m[2 * q].y, 0.f, 0.f};
+    if constexpr (2 * q + 1 < D / 2) { t.z = m[2 * q + 1].x; t.w = m[2 * q + 1].y; }
+    *row_ptr(base, row + q, lane) = t;
+  });
+}
+
 template <int D>
 __device__ __forceinline__ void load_vec(const float* base, long long row, int lane, float (&m)[D]) {
   static_for<0, (D + 3) / 4>([&](auto q_) {

@@ -99,7 +99,7 @@ __global__ void gns_pack_inputs_kernel(const int* __restrict__ topo, const float
 // The fused forward kernel.
 // ------------------------------------------------------------------------------------------------
 template <int D, int H, bool MULTI>
-__global__ void __launch_bounds__(GNS_FWD_THREADS) gns_forward_kernel(GnsFwdArgs A) {
+__global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwdArgs A) {
   using C = GnsDims<D, H, MULTI>;
   constexpr int MQ = C::MQ, RB = C::RB;
   const int lane = threadIdx.x & 63;
@@ -144,41 +144,41 @@ __global__ void __launch_bounds__(GNS_FWD_THREADS) gns_forward_kernel(GnsFwdArgs
     for (int n = n0; n < n1; ++n) {
       const long long rr = state_row(rs, n), wr = state_row(ws, n);
       const f4 s0 = *row_ptr(A.state, rr, lane);
-      float m[D];
-      load_vec<D>(A.state, rr + 1, lane, m);
-      f2 S[C::NPHI][C::PHI_OUTP / 2];
-#pragma unroll
-      for (int f = 0; f < C::NPHI; ++f)
-#pragma unroll
-        for (int j = 0; j < C::PHI_OUTP / 2; ++j) S[f][j] = f2{0.f, 0.f};
+      f2 m[D / 2];
+      load_pairs<D>(A.state, rr + 1, lane, m);
       const int p0 = in_ptr[n], p1 = in_ptr[n + 1];
-      for (int p = p0; p < p1; ++p) {                  // messages of the lines ending at n (main.py:155-163)
-        const f4 e0 = *row_ptr(IN, row_ein + 3LL * p, lane), e1 = *row_ptr(IN, row_ein + 3LL * p + 1, lane);
-        float x[C::PHI_IN];
+      float upd_theta, upd_v;
+      f2 upd_m[D / 2];
+      f2 S[C::PHI_OUTP / 2];        // message sum of the family in flight (one family at a time: fewer live registers)
+      auto message_sum = [&](auto f_) {                // sum over the lines ending at n of phi_f([m | r x b tau shift])  (main.py:155-163)
+        constexpr int f = decltype(f_)::value;
 #pragma unroll
-        for (int i = 0; i < D; ++i) x[i] = m[i];
-        x[D] = e0.x; x[D + 1] = e0.y; x[D + 2] = e0.z; x[D + 3] = e0.w; x[D + 4] = e1.x;
-        static_for<0, C::NPHI>([&](auto f_) {
-          constexpr int f = decltype(f_)::value;
+        for (int j = 0; j < C::PHI_OUTP / 2; ++j) S[j] = f2{0.f, 0.f};
+        for (int p = p0; p < p1; ++p) {
+          const f4 e0 = *row_ptr(IN, row_ein + 3LL * p, lane), e1 = *row_ptr(IN, row_ein + 3LL * p + 1, lane);
+          f2 x[(C::PHI_IN + 1) / 2];
+#pragma unroll
+          for (int i = 0; i < D / 2; ++i) x[i] = m[i];
+          x[D / 2] = f2{e0.x, e0.y}; x[D / 2 + 1] = f2{e0.z, e0.w}; x[D / 2 + 2] = f2{e1.x, 0.f};
           f2 a1[H / 2], a2[H / 2], y[C::PHI_OUTP / 2];
           mlp_fwd<C::PHI_IN, H, C::PHI_OUTP>(PT + A.t_off[f] + koff * A.t_sz[f], x, a1, a2, y);
 #pragma unroll
-          for (int j = 0; j < C::PHI_OUTP / 2; ++j) S[f][j] += y[j];
-        });
-      }
-      float upd_theta, upd_v;
-      f2 upd_m[D / 2];
+          for (int j = 0; j < C::PHI_OUTP / 2; ++j) S[j] += y[j];
+        }
+      };
+      if constexpr (!MULTI) message_sum(std::integral_constant<int, 0>{});
       static_for<0, 3>([&](auto l_) {                  // l: 0 = L_theta, 1 = L_v, 2 = L_m   (main.py:173-180)
         constexpr int l = decltype(l_)::value;
         constexpr int fphi = MULTI ? (l == 0 ? 1 : (l == 1 ? 0 : 2)) : 0;   // phi_theta, phi_v, phi_m
-        float x[C::L_IN];
-        x[0] = s0.x; x[1] = s0.y; x[2] = s0.z; x[3] = s0.w;
+        if constexpr (MULTI) message_sum(std::integral_constant<int, fphi>{});
+        f2 x[C::L_IN / 2];
+        x[0] = f2{s0.x, s0.y}; x[1] = f2{s0.z, s0.w};
 #pragma unroll
-        for (int i = 0; i < D; ++i) x[4 + i] = m[i];
+        for (int i = 0; i < D / 2; ++i) x[2 + i] = m[i];
 #pragma unroll
-        for (int i = 0; i < D; ++i) {
-          if constexpr (MULTI) x[4 + D + i] = (i & 1) ? S[fphi][i / 2].y : S[fphi][i / 2].x;
-          else x[4 + D + i] = (i == 0) ? S[0][0].x : 0.f;           // [E,1] scattered into column 0 (main.py:170)
+        for (int i = 0; i < D / 2; ++i) {
+          if constexpr (MULTI) x[2 + D / 2 + i] = S[i];
+          else x[2 + D / 2 + i] = (i == 0) ? f2{S[0].x, 0.f} : f2{0.f, 0.f};   // [E,1] scattered into column 0 (main.py:170)
         }
         f2 a1[H / 2], a2[H / 2];
         if constexpr (l < 2) {
@@ -192,9 +192,10 @@ __global__ void __launch_bounds__(GNS_FWD_THREADS) gns_forward_kernel(GnsFwdArgs
       const float th_new = s0.y + upd_theta;                          // main.py:182
       const float v_new = is_gen[n] ? s0.x : s0.x + upd_v;           // main.py:184-186
       *row_ptr(A.state, wr, lane) = f4{v_new, th_new, 0.f, 0.f};
-      float m_new[D];
-      static_for<0, D>([&](auto i_) { constexpr int i = decltype(i_)::value; m_new[i] = m[i] + lane_of<i>(upd_m); });   // main.py:188
-      store_vec<D>(A.state, wr + 1, lane, m_new);
+      f2 m_new[D / 2];
+#pragma unroll
+      for (int i = 0; i < D / 2; ++i) m_new[i] = m[i] + upd_m[i];     // main.py:188
+      store_pairs<D>(A.state, wr + 1, lane, m_new);
     }
     __syncthreads();   // every bus of the 64 grids now has v_{k+1}, theta_{k+1}
 
