@@ -95,11 +95,16 @@ __device__ __forceinline__ void dw_accumulate(float* rec, int lane, const DwTile
 #endif
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
+#ifndef GNS_ABLATE_RECWRITE
     if ((lane >> 5) == half) rec_write<IN, H, OUT, OUTP>(rec, lane & 31, x, a1, a2, g1, g2, g3);
+#else
+    if ((lane >> 5) == half) asm volatile("" :: "v"(x[0]), "v"(a1[0]), "v"(a2[0]), "v"(g1[0]), "v"(g2[0]), "v"(g3[0]));
+#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const float* rw = rec + T.woff;
     const float* ru = rec + T.uoff;
+#ifndef GNS_ABLATE_ENGINE
 #pragma unroll 4
     for (int r = 0; r < GNS_REC_ROWS; ++r) {
       const f4 w = *reinterpret_cast<const f4*>(rw + r * R::RS);
@@ -110,6 +115,9 @@ __device__ __forceinline__ void dw_accumulate(float* rec, int lane, const DwTile
       acc[2][0] = __builtin_elementwise_fma(splat(w.z), u0, acc[2][0]); acc[2][1] = __builtin_elementwise_fma(splat(w.z), u1, acc[2][1]);
       acc[3][0] = __builtin_elementwise_fma(splat(w.w), u0, acc[3][0]); acc[3][1] = __builtin_elementwise_fma(splat(w.w), u1, acc[3][1]);
     }
+#else
+    acc[0][0] += f2{rw[0], ru[0]};
+#endif
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
@@ -173,6 +181,13 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
   float* slab = A.slab + ((long long)blockIdx.x * W + wave) * A.slab_floats;
   const float invN = 1.0f / (float)N;
 
+#ifdef GNS_STAMPS
+  long long tph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = clock64();
+#define STAMP(i) { const long long tn = clock64(); tph[i] += tn - tlast; tlast = tn; }
+#else
+#define STAMP(i)
+#endif
   for (long long g = blockIdx.x; g < A.G; g += gridDim.x) {
     const long long in_base = g * R, row_ein = in_base + 3LL * N, row_eout = row_ein + 3LL * E, row_grid = row_eout + E;
     const long long b = g * GNS_LANES + lane;
@@ -214,15 +229,21 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
         const f4 b1 = *row_ptr(IN, in_base + 3LL * n + 1, lane);            // Pmin,Pset,Pmax per bus
         lb += a0.z * (low2 ? 2.f * (b1.y - b1.x) : 2.f * (b1.z - b1.y));    // d Pg_new / d lambda  (main.py:53-57)
       }
+      STAMP(0)
       red[k & 1][wave][lane] = lb;
       __syncthreads();
+      STAMP(1)
       float lbar = 0.f;
 #pragma unroll
       for (int w = 0; w < W; ++w) lbar += red[k & 1][w][lane];
       const float pgbar = lbar / (low1 ? 2.f * (gsum.y - gsum.z) : 2.f * (gsum.w - gsum.y));   // d lambda / d p_global (main.py:47-51)
 
       // ---------------- Pb-edge ----------------
+#ifdef GNS_ABLATE_PHYS
+      for (int p = e0; p < e0; ++p) {
+#else
       for (int p = e0; p < e1; ++p) {
+#endif
         const int s = in_src[p], t = in_dst[p], ia = in_a[p], ib = in_b[p], q = p2q[p], ic = out_c[q], id = out_d[q];
         const f4 e1v = *row_ptr(IN, row_ein + 3LL * p + 1, lane);           // shift_e, y_s, tau_s, sh_s
         const f4 o0 = *row_ptr(IN, row_eout + q, lane);                      // y_t, tau_t, sh_t, b_t
@@ -262,7 +283,9 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
         *slot_ptr(0, p) = dvs; *slot_ptr(1, p) = dvt; *slot_ptr(2, p) = dths; *slot_ptr(3, p) = dtht;
         *slot_ptr(4, p) = dbar; *slot_ptr(5, p) = dbar2;
       }
+      STAMP(2)
       __syncthreads();
+      STAMP(3)
 
       // ---------------- Ub, pass G: every bus completes d/d(v,theta)_{k+1} from the per-line adjoints --------------
       for (int n = n0; n < n1; ++n) {
@@ -270,15 +293,35 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
         const f4 a0 = *row_ptr(A.adj, ar, lane);
         float vbar = a0.x, thbar = a0.y;
         const float dpb = a0.z;
+        // The three lists are summed 8 entries at a time with clamped indices, so that 8 independent loads are in
+        // flight; one entry per iteration would pay the full (scalar index -> vector load) latency per entry.
         const int p0 = in_ptr[n], p1 = in_ptr[n + 1];
-        for (int p = p0; p < p1; ++p) { vbar += *slot_ptr(1, p); thbar += *slot_ptr(3, p); }
+        for (int p = p0; p < p1; p += 4) {
+          float a[4], b[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { const int pp = min(p + j, p1 - 1); a[j] = *slot_ptr(1, pp); b[j] = *slot_ptr(3, pp); }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (p + j < p1) { vbar += a[j]; thbar += b[j]; }
+        }
         const int q0 = out_ptr[n], q1 = out_ptr[n + 1];
-        for (int q = q0; q < q1; ++q) { const int p = q2p[q]; vbar += *slot_ptr(0, p); thbar += *slot_ptr(2, p); }
+        for (int q = q0; q < q1; q += 4) {
+          float a[4], b[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { const int p = q2p[min(q + j, q1 - 1)]; a[j] = *slot_ptr(0, p); b[j] = *slot_ptr(2, p); }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (q + j < q1) { vbar += a[j]; thbar += b[j]; }
+        }
         const int i0 = incd_ptr[n], i1 = incd_ptr[n + 1];
-        for (int i = i0; i < i1; ++i) {
-          const int code = incd[i];
-          const float val = *slot_ptr((code & 2) ? 5 : 4, code >> 2);
-          thbar += (code & 1) ? -val : val;
+        for (int i = i0; i < i1; i += 8) {
+          float a[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int code = incd[min(i + j, i1 - 1)];
+            const float val = *slot_ptr((code & 2) ? 5 : 4, code >> 2);
+            a[j] = (code & 1) ? -val : val;
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) if (i + j < i1) thbar += a[j];
         }
         const f4 s1 = *row_ptr(A.state, state_row(k + 1, n), lane);
         const float Gs = row_ptr(IN, in_base + 3LL * n, lane)->z;
@@ -286,6 +329,7 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
         *row_ptr(A.adj, ar, lane) = f4{vbar, thbar, dpb, 0.f};
       }
 
+      STAMP(4)
       // ---------------- Ub, one pass over the buses per network family (main.py:155-188 recomputed + reversed) ------
       // Family-outer order keeps the 4x4 weight-gradient tiles of (L_l, phi_f) in registers for the whole pass.
       auto edge_input = [&](int p, const f2 (&m)[D / 2], f2 (&x)[(C::PHI_IN + 1) / 2]) {
@@ -326,7 +370,11 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
             f2 (&S)[D / 2] = reinterpret_cast<f2 (&)[D / 2]>(x[2 + D / 2]);
 #pragma unroll
             for (int j = 0; j < D / 2; ++j) S[j] = f2{0.f, 0.f};
+#ifdef GNS_ABLATE_MSGSUM
+            for (int p = p0; p < p0; ++p) {
+#else
             for (int p = p0; p < p1; ++p) {                     // message sum of family fphi (main.py:155-163)
+#endif
               f2 xe[(C::PHI_IN + 1) / 2], a1[H / 2], a2[H / 2], y[C::PHI_OUTP / 2];
               edge_input(p, m, xe);
               mlp_fwd<C::PHI_IN, H, C::PHI_OUTP>(PT + A.t_off[fphi] + koff * A.t_sz[fphi], xe, a1, a2, y);
@@ -354,7 +402,11 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
             dw_accumulate<C::L_IN, H, OUT, OUTP>(rec, lane, TL, accL, x, a1, a2, g1, g2, g3);
           }
           if constexpr (MULTI) {
+#ifdef GNS_ABLATE_MSGBWD
+            for (int p = p0; p < p0; ++p) {
+#else
             for (int p = p0; p < p1; ++p) {                     // back through the messages of the lines ending at n
+#endif
               f2 xe[(C::PHI_IN + 1) / 2], a1[H / 2], a2[H / 2], y[C::PHI_OUTP / 2], g2[H / 2], g1[H / 2];
               edge_input(p, m, xe);
               mlp_fwd<C::PHI_IN, H, C::PHI_OUTP>(PT + A.t_off[fphi] + koff * A.t_sz[fphi], xe, a1, a2, y);
@@ -368,6 +420,7 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
         }
         dw_flush<C::L_IN, H, OUT>(lane, TL, accL, slab + A.f_off[C::NPHI + l] + koff * A.f_sz[C::NPHI + l]);
         if constexpr (MULTI) dw_flush<C::PHI_IN, H, C::PHI_OUT>(lane, TP, accP, slab + A.f_off[fphi] + koff * A.f_sz[fphi]);
+        STAMP(5 + l)
       });
       if constexpr (!MULTI) {                                  // the single phi: its output adjoint is the sum over the three L nets
         const DwTile TP = dw_tile<C::PHI_IN, H, C::PHI_OUT>(lane);
@@ -399,9 +452,13 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
         *row_ptr(A.adj, ar, lane) = f4{a0.x + xsum.x, a0.y + xsum.y, xsum.z, 0.f};     // main.py:182,186 identity paths
         *row_ptr(A.adj, ar + 1, lane) = f4{0.f, 0.f, 0.f, 0.f};
       }
+      STAMP(8)
     }
     __syncthreads();
   }
+#ifdef GNS_STAMPS
+  if (lane == 0) for (int i = 0; i < 10; ++i) A.slots[((long long)blockIdx.x * W + wave) * 10 + i] = (float)tph[i];   // diagnostic build only: slots are dead by now
+#endif
 }
 
 // ---- slab reduction: grad[i] += sum over slabs, two fixed-order stages (bitwise reproducible) ----------

@@ -34,16 +34,23 @@ __device__ __forceinline__ int opaque_zero() {
   return z;
 }
 
+// Scalar loads return out of order, so the only wait hipcc can emit for them is lgkmcnt(0) = "everything".  To let
+// the next chunk's load fly during this chunk's FMAs, the wait for the CURRENT chunk has to come before the next
+// load is issued: touching one of its registers forces exactly that.
+__device__ __forceinline__ void touch(const f16v& v) { asm volatile("" ::"s"(v[0])); }
+
 template <int NF, class F>
 __device__ __forceinline__ void stream_pairs(cfp p, F&& f) {
   constexpr int NCH = (NF + 15) / 16;
+  p += opaque_zero();
   f16v bufA, bufB;
-  bufA = *(cf16p)(p + opaque_zero());
+  bufA = *(cf16p)(p);
   static_for<0, NCH>([&](auto c_) {
     constexpr int c = decltype(c_)::value;
     f16v& cur = (c & 1) ? bufB : bufA;
     f16v& nxt = (c & 1) ? bufA : bufB;
-    if constexpr (c + 1 < NCH) nxt = *(cf16p)(p + 16 * (c + 1) + opaque_zero());   // a fresh opaque zero per chunk: IR passes cannot batch the loads
+    touch(cur);
+    if constexpr (c + 1 < NCH) nxt = *(cf16p)(p + 16 * (c + 1));
     __builtin_amdgcn_sched_barrier(0);
     static_for<0, 8>([&](auto t_) {
       constexpr int t = decltype(t_)::value;
