@@ -98,11 +98,20 @@ def main():
     import ctypes
     import opf_graph_neural_solver_amd as amd
 
+    # Rehearsal switches for a ONE-GPU box (never set by the driver): every rank uses cuda:0 and the collective runs
+    # over gloo, which exercises rendezvous / barrier / all-reduce / max-over-ranks / JSON exactly like the RCCL run.
+    share = os.environ.get('GNS_BENCH_SHARE_GPU') == '1'
+    backend = os.environ.get('GNS_BENCH_BACKEND', 'nccl')
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)     # RCCL over xGMI
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     lib = amd.load_library()
 
     torch.manual_seed(0)                       # identical replicas on every rank

@@ -37,33 +37,36 @@ template <int IN, int H, int OUT, int OUTP>
 __device__ __forceinline__ void rec_write(float* rec, int row, const f2 (&x)[(IN + 1) / 2], const f2 (&a1)[H / 2], const f2 (&a2)[H / 2],
                                           const f2 (&g1)[H / 2], const f2 (&g2)[H / 2], const f2 (&g3)[OUTP / 2]) {
   using R = RecLay<IN, H, OUT>;
-  f4* dst = reinterpret_cast<f4*>(rec + row * R::RS);
-  static_for<0, R::raw / 4>([&](auto q_) {
+  // 8-byte stores straight from the aligned register pairs the MLPs work on (16-byte stores would first need
+  // four v_mov per store to build a register quad)
+  f2* dst = reinterpret_cast<f2*>(rec + row * R::RS);
+  static_for<0, R::raw / 2>([&](auto q_) {
     constexpr int q = decltype(q_)::value;
-    float e[4];
-    static_for<0, 4>([&](auto c_) {
-      constexpr int c = decltype(c_)::value;
-      constexpr int o = 4 * q + c;
-      if constexpr (o < R::oA1) {
-        if constexpr (o < IN) e[c] = lane_of<o>(x); else e[c] = (o == IN) ? 1.f : 0.f;
-      } else if constexpr (o < R::oA2) {
-        constexpr int i = o - R::oA1;
-        if constexpr (i < H) e[c] = lane_of<i>(a1); else e[c] = (i == H) ? 1.f : 0.f;
-      } else if constexpr (o < R::oG1) {
-        constexpr int i = o - R::oA2;
-        if constexpr (i < H) e[c] = lane_of<i>(a2); else e[c] = (i == H) ? 1.f : 0.f;
-      } else if constexpr (o < R::oG2) {
-        constexpr int i = o - R::oG1;
-        if constexpr (i < H) e[c] = lane_of<i>(g1); else e[c] = 0.f;
-      } else if constexpr (o < R::oG3) {
-        constexpr int i = o - R::oG2;
-        if constexpr (i < H) e[c] = lane_of<i>(g2); else e[c] = 0.f;
-      } else {
-        constexpr int i = o - R::oG3;
-        if constexpr (i < OUT) e[c] = lane_of<i>(g3); else e[c] = 0.f;
-      }
-    });
-    dst[q] = f4{e[0], e[1], e[2], e[3]};
+    constexpr int o = 2 * q;               // even element index; fields start at multiples of 4
+    f2 e;
+    if constexpr (o < R::oA1) {
+      if constexpr (o + 1 < IN) e = x[q];
+      else if constexpr (o < IN) e = f2{x[q].x, 1.f};            // IN odd: last input then the 1 of the bias column
+      else e = (o == IN) ? f2{1.f, 0.f} : f2{0.f, 0.f};
+    } else if constexpr (o < R::oA2) {
+      constexpr int i = o - R::oA1;
+      if constexpr (i < H) e = a1[i / 2]; else e = (i == H) ? f2{1.f, 0.f} : f2{0.f, 0.f};
+    } else if constexpr (o < R::oG1) {
+      constexpr int i = o - R::oA2;
+      if constexpr (i < H) e = a2[i / 2]; else e = (i == H) ? f2{1.f, 0.f} : f2{0.f, 0.f};
+    } else if constexpr (o < R::oG2) {
+      constexpr int i = o - R::oG1;
+      if constexpr (i < H) e = g1[i / 2]; else e = f2{0.f, 0.f};
+    } else if constexpr (o < R::oG3) {
+      constexpr int i = o - R::oG2;
+      if constexpr (i < H) e = g2[i / 2]; else e = f2{0.f, 0.f};
+    } else {
+      constexpr int i = o - R::oG3;
+      if constexpr (i + 1 < OUT) e = g3[i / 2];
+      else if constexpr (i < OUT) e = f2{g3[i / 2].x, 0.f};
+      else e = f2{0.f, 0.f};
+    }
+    dst[q] = e;
   });
 }
 

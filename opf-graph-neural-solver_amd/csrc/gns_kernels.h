@@ -4,7 +4,7 @@
 #include "../../include/gns_hip.h"
 #include "gns_common.h"
 
-#define GNS_FWD_THREADS 512      // default: 8 waves split the buses of 64 grids (GNS_FWD_WAVES=16 tries 16)
+#define GNS_FWD_THREADS 1024     // default: 16 waves (4 per SIMD) split the buses of 64 grids; GNS_FWD_WAVES=8 selects 8
 #define GNS_FWD_MAX_THREADS 1024 // register budget of the forward kernel: 128 VGPRs -> 4 waves/SIMD
 #define GNS_BWD_THREADS 512
 #define GNS_MAX_K 64
