@@ -113,7 +113,7 @@ extern "C" int gns_forward(const gns_config* cfg, const void* topo_dev, const fl
   float* pt = (float*)(ws + L.off_pt);
   float* pn = (float*)(ws + L.off_pn);
   float* pin = (float*)(ws + L.off_in);
-  rc = gns_launch_pack_params(params, pt, pn, fam, K, h, st);
+  rc = gns_launch_pack_params(params, pt, pn, fam, K, d, h, st);
   if (rc != GNS_OK) return rc;
   rc = gns_launch_pack_inputs((const int*)topo_dev, buses, lines, generators, pin, N, E, Gn, Bt, L.groups, st);
   if (rc != GNS_OK) return rc;
@@ -164,7 +164,7 @@ extern "C" int gns_backward(const gns_config* cfg, const void* topo_dev, const f
   A.adj = (float*)(bw + B.off_adj); A.slots = (float*)(bw + B.off_slots); A.slab = (float*)(bw + B.off_slab);
   for (int i = 0; i < fam.nfam; ++i) {
     A.t_off[i] = fam.t_off[i]; A.t_sz[i] = fam.t_sz[i]; A.n_off[i] = fam.n_off[i]; A.n_sz[i] = fam.n_sz[i];
-    A.f_off[i] = fam.flat_off[i]; A.f_sz[i] = fam.flat_sz[i];
+    A.g_off[i] = fam.g_off[i]; A.g_sz[i] = fam.g_sz[i];
   }
   for (int k = 0; k < K; ++k) A.gw[k] = (float)std::pow((double)cfg->gamma, (double)(K - k));
   A.Bt = Bt; A.G = B.groups; A.slab_floats = B.slab_floats; A.N = N; A.E = E; A.K = K;
@@ -173,5 +173,6 @@ extern "C" int gns_backward(const gns_config* cfg, const void* topo_dev, const f
   rc = gns_launch_backward(d, h, cfg->multiple_phi, A, blocks, st);
   prof_mark(1, false, st);
   if (rc != GNS_OK) return rc;
-  return gns_launch_reduce(A.slab, (float*)(bw + B.off_part), grad_params, nslab, B.slab_floats, fam.flat_total, st);
+  return gns_launch_reduce(A.slab, (float*)(bw + B.off_part), (float*)(bw + B.off_tmp), params, grad_params, nslab, B.slab_floats,
+                           fam, K, d, h, st);
 }

@@ -70,6 +70,45 @@ __device__ __forceinline__ void rec_write(float* rec, int row, const f2 (&x)[(IN
   });
 }
 
+// ---- phi' (two layers): record [x|1, a1|1, g1, g2], tiles of dW1|db1 and dW2|db2 -----------------------------------
+template <int IN, int H>
+struct RecLay2 {
+  static constexpr int XP = (IN + 1 + 3) / 4 * 4, HP = (H + 1 + 3) / 4 * 4;
+  static constexpr int oX = 0, oA1 = XP, oG1 = oA1 + HP, oG2 = oG1 + HP;
+  static constexpr int raw = oG2 + HP;
+  static constexpr int RS = ((raw / 4) | 1) * 4;
+  static constexpr int TX = XP / 4, TH = HP / 4;
+  static constexpr int T1 = TH * TX, T2 = TH * TH, NT = T1 + T2;
+  static_assert(NT <= 64, "one pass per network");
+};
+
+template <int IN, int H>
+__device__ __forceinline__ void rec_write2(float* rec, int row, const f2 (&x)[(IN + 1) / 2], const f2 (&a1)[H / 2],
+                                           const f2 (&g1)[H / 2], const f2 (&g2)[H / 2]) {
+  using R = RecLay2<IN, H>;
+  f2* dst = reinterpret_cast<f2*>(rec + row * R::RS);
+  static_for<0, R::raw / 2>([&](auto q_) {
+    constexpr int q = decltype(q_)::value;
+    constexpr int o = 2 * q;
+    f2 e;
+    if constexpr (o < R::oA1) {
+      if constexpr (o + 1 < IN) e = x[q];
+      else if constexpr (o < IN) e = f2{x[q].x, 1.f};
+      else e = (o == IN) ? f2{1.f, 0.f} : f2{0.f, 0.f};
+    } else if constexpr (o < R::oG1) {
+      constexpr int i = o - R::oA1;
+      if constexpr (i < H) e = a1[i / 2]; else e = (i == H) ? f2{1.f, 0.f} : f2{0.f, 0.f};
+    } else if constexpr (o < R::oG2) {
+      constexpr int i = o - R::oG1;
+      if constexpr (i < H) e = g1[i / 2]; else e = f2{0.f, 0.f};
+    } else {
+      constexpr int i = o - R::oG2;
+      if constexpr (i < H) e = g2[i / 2]; else e = f2{0.f, 0.f};
+    }
+    dst[q] = e;
+  });
+}
+
 // Weight gradient of one LearningBlock for the 64 grids of this wave: dW += sum_grids g (x) input.
 // Lane t < NT owns the 4x4 tile t of [dW1|db1], [dW2|db2] or [dW4|db4]; the tile lives in registers across all
 // the rows (buses / lines) a wave handles in one reverse step and is flushed once, into the wave's slab in the
@@ -87,6 +126,27 @@ __device__ __forceinline__ DwTile dw_tile(int lane) {
   return T;
 }
 
+// one half-wave of records is in LDS: every lane adds 32 rank-1 updates to its 4x4 tile
+template <int RS>
+__device__ __forceinline__ void dw_sweep(const float* rec, const DwTile& T, f2 (&acc)[4][2]) {
+  const float* rw = rec + T.woff;
+  const float* ru = rec + T.uoff;
+#ifndef GNS_ABLATE_ENGINE
+#pragma unroll 4
+  for (int r = 0; r < GNS_REC_ROWS; ++r) {
+    const f4 w = *reinterpret_cast<const f4*>(rw + r * RS);
+    const f4 u = *reinterpret_cast<const f4*>(ru + r * RS);
+    const f2 u0 = f2{u.x, u.y}, u1 = f2{u.z, u.w};
+    acc[0][0] = __builtin_elementwise_fma(splat(w.x), u0, acc[0][0]); acc[0][1] = __builtin_elementwise_fma(splat(w.x), u1, acc[0][1]);
+    acc[1][0] = __builtin_elementwise_fma(splat(w.y), u0, acc[1][0]); acc[1][1] = __builtin_elementwise_fma(splat(w.y), u1, acc[1][1]);
+    acc[2][0] = __builtin_elementwise_fma(splat(w.z), u0, acc[2][0]); acc[2][1] = __builtin_elementwise_fma(splat(w.z), u1, acc[2][1]);
+    acc[3][0] = __builtin_elementwise_fma(splat(w.w), u0, acc[3][0]); acc[3][1] = __builtin_elementwise_fma(splat(w.w), u1, acc[3][1]);
+  }
+#else
+  acc[0][0] += f2{rw[0], ru[0]};
+#endif
+}
+
 template <int IN, int H, int OUT, int OUTP>
 __device__ __forceinline__ void dw_accumulate(float* rec, int lane, const DwTile& T, f2 (&acc)[4][2], const f2 (&x)[(IN + 1) / 2],
                                               const f2 (&a1)[H / 2], const f2 (&a2)[H / 2], const f2 (&g1)[H / 2],
@@ -100,29 +160,65 @@ __device__ __forceinline__ void dw_accumulate(float* rec, int lane, const DwTile
   for (int half = 0; half < 2; ++half) {
 #ifndef GNS_ABLATE_RECWRITE
     if ((lane >> 5) == half) rec_write<IN, H, OUT, OUTP>(rec, lane & 31, x, a1, a2, g1, g2, g3);
-#else
-    if ((lane >> 5) == half) asm volatile("" :: "v"(x[0]), "v"(a1[0]), "v"(a2[0]), "v"(g1[0]), "v"(g2[0]), "v"(g3[0]));
 #endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const float* rw = rec + T.woff;
-    const float* ru = rec + T.uoff;
-#ifndef GNS_ABLATE_ENGINE
-#pragma unroll 4
-    for (int r = 0; r < GNS_REC_ROWS; ++r) {
-      const f4 w = *reinterpret_cast<const f4*>(rw + r * R::RS);
-      const f4 u = *reinterpret_cast<const f4*>(ru + r * R::RS);
-      const f2 u0 = f2{u.x, u.y}, u1 = f2{u.z, u.w};
-      acc[0][0] = __builtin_elementwise_fma(splat(w.x), u0, acc[0][0]); acc[0][1] = __builtin_elementwise_fma(splat(w.x), u1, acc[0][1]);
-      acc[1][0] = __builtin_elementwise_fma(splat(w.y), u0, acc[1][0]); acc[1][1] = __builtin_elementwise_fma(splat(w.y), u1, acc[1][1]);
-      acc[2][0] = __builtin_elementwise_fma(splat(w.z), u0, acc[2][0]); acc[2][1] = __builtin_elementwise_fma(splat(w.z), u1, acc[2][1]);
-      acc[3][0] = __builtin_elementwise_fma(splat(w.w), u0, acc[3][0]); acc[3][1] = __builtin_elementwise_fma(splat(w.w), u1, acc[3][1]);
-    }
-#else
-    acc[0][0] += f2{rw[0], ru[0]};
-#endif
+    dw_sweep<R::RS>(rec, T, acc);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int IN, int H>
+__device__ __forceinline__ DwTile dw_tile2(int lane) {
+  using R = RecLay2<IN, H>;
+  DwTile T;
+  int t = lane < R::NT ? lane : 0;
+  if (t < R::T1) { T.kind = 0; T.cb = t / R::TX; T.ib = t % R::TX; T.woff = R::oG1 + 4 * T.cb; T.uoff = R::oX + 4 * T.ib; }
+  else { t -= R::T1; T.kind = 1; T.cb = t / R::TH; T.ib = t % R::TH; T.woff = R::oG2 + 4 * T.cb; T.uoff = R::oA1 + 4 * T.ib; }
+  return T;
+}
+
+template <int IN, int H>
+__device__ __forceinline__ void dw_accumulate2(float* rec, int lane, const DwTile& T, f2 (&acc)[4][2], const f2 (&x)[(IN + 1) / 2],
+                                               const f2 (&a1)[H / 2], const f2 (&g1)[H / 2], const f2 (&g2)[H / 2]) {
+  using R = RecLay2<IN, H>;
+#ifdef GNS_ABLATE_DW
+  asm volatile("" :: "v"(x[0]), "v"(a1[0]), "v"(g1[0]), "v"(g2[0]));
+  return;
+#endif
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#ifndef GNS_ABLATE_RECWRITE
+    if ((lane >> 5) == half) rec_write2<IN, H>(rec, lane & 31, x, a1, g1, g2);
+#endif
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    dw_sweep<R::RS>(rec, T, acc);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// phi' tile -> folded-gradient block W1[H][IN] b1[H] W2[H][H] b2[H]
+template <int IN, int H>
+__device__ __forceinline__ void dw_flush2(int lane, const DwTile& T, const f2 (&acc)[4][2], float* slab_blk) {
+  using R = RecLay2<IN, H>;
+  if (lane < R::NT) {
+    constexpr int ob1 = IN * H, oW2 = ob1 + H, ob2 = oW2 + H * H;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int c = 4 * T.cb + a;
+#pragma unroll
+      for (int bq = 0; bq < 4; ++bq) {
+        const int i = 4 * T.ib + bq;
+        const float val = (bq & 1) ? acc[a][bq >> 1].y : acc[a][bq >> 1].x;
+        int idx = -1;
+        if (T.kind == 0) { if (c < H) idx = (i < IN) ? c * IN + i : (i == IN ? ob1 + c : -1); }
+        else { if (c < H) idx = (i < H) ? oW2 + c * H + i : (i == H ? ob2 + c : -1); }
+        if (idx >= 0) slab_blk[idx] += val;
+      }
+    }
   }
 }
 
@@ -176,8 +272,8 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
   const long long R = gns_in_rows(N, E);
   const float* IN = A.in;
 
-  constexpr int RECF = GNS_REC_ROWS * gns_cmax(gns_cmax(RecLay<C::L_IN, H, D>::RS, RecLay<C::L_IN, H, 1>::RS),
-                                                 RecLay<C::PHI_IN, H, C::PHI_OUT>::RS);
+  constexpr int RECF = GNS_REC_ROWS * gns_cmax(gns_cmax(RecLay<C::LF_IN, H, D>::RS, RecLay<C::LF_IN, H, 1>::RS),
+                                                 RecLay2<C::PHI_IN, H>::RS);
   __shared__ __attribute__((aligned(16))) float rec_all[W][RECF];
   __shared__ float red[2][W][GNS_LANES];
   float* rec = rec_all[wave];
@@ -198,7 +294,9 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
     const float gt = (live && A.g_total) ? A.g_total[b] : 0.f;
     const float gl = (live && A.g_last) ? A.g_last[b] : 0.f;
     auto state_row = [&](int slot, int n) { return (((long long)slot * A.G + g) * N + n) * RB; };
-    constexpr int RBA = RB + 1;      // (vbar, thbar, dpbar, -) | input-adjoint sums of this step | mbar
+    // rows per bus: (vbar, thbar, dpbar, -) | input-adjoint sums of this step | [single phi: adjoint of the hidden sum] | mbar
+    constexpr int RHB = MULTI ? 0 : C::HQ;
+    constexpr int RBA = RB + 1 + RHB, RM = 2 + RHB;
     auto adj_row = [&](int n) { return (g * N + n) * RBA; };
     auto slot_ptr = [&](int j, int p) { return A.slots + ((g * 6 + j) * E + p) * GNS_LANES + lane; };
     const f4 gsum = *row_ptr(IN, row_grid, lane);
@@ -211,7 +309,7 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
       const long long ar = adj_row(n);
       *row_ptr(A.adj, ar, lane) = f4{vb, tb, 0.f, 0.f};
 #pragma unroll
-      for (int q = 0; q < 1 + C::MQ; ++q) *row_ptr(A.adj, ar + 1 + q, lane) = f4{0.f, 0.f, 0.f, 0.f};
+      for (int q = 0; q < RBA - 1; ++q) *row_ptr(A.adj, ar + 1 + q, lane) = f4{0.f, 0.f, 0.f, 0.f};
     }
 
     for (int k = K - 1; k >= 0; --k) {
@@ -347,113 +445,116 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
         constexpr int OUT = (l == 2) ? D : 1, OUTP = OUT + (OUT & 1);
         // after the last step nothing reads m_K: L_m.{K-1} / phi_m.{K-1} get no gradient (reference: .grad is None)
         if (l == 2 && k == K - 1) return;
-        const DwTile TL = dw_tile<C::L_IN, H, OUT>(lane);
-        const DwTile TP = dw_tile<C::PHI_IN, H, C::PHI_OUT>(lane);
+        const DwTile TL = dw_tile<C::LF_IN, H, OUT>(lane);
+        const DwTile TP = dw_tile2<C::PHI_IN, H>(lane);
         f2 accL[4][2], accP[4][2];
         zero_acc(accL); zero_acc(accP);
         for (int n = n0; n < n1; ++n) {
           const long long ar = adj_row(n), rr = state_row(k, n);
           const f4 a0 = *row_ptr(A.adj, ar, lane);
-          f4 xsum = *row_ptr(A.adj, ar + 1, lane);            // (d/dv, d/dtheta, d/ddp of the L inputs so far, gS of the single phi)
+          f4 xsum = *row_ptr(A.adj, ar + 1, lane);            // d/dv, d/dtheta, d/ddp of the L inputs so far
           const f4 s0 = *row_ptr(A.state, rr, lane);
           f2 m[D / 2];
           load_pairs<D>(A.state, rr + 1, lane, m);
-          // gx is the adjoint of the L-net input [v theta | dp dq | m | message sum]; its m part starts as d/dm_{k+1}
-          // (identity path main.py:188) and keeps accumulating, so no separate copy of the latent adjoint is live
-          f2 gx[C::L_IN / 2];
+          // gx = adjoint of the L' input [v theta | dp dq | m | sum_e h_e | deg].  Its m part starts as d/dm_{k+1}
+          // (identity path main.py:188) and keeps accumulating; its hidden-sum part is what every line ending at n receives.
+          constexpr int XL = (C::LF_IN + 1) / 2;
+          f2 gx[XL];
           f2 (&macc)[D / 2] = reinterpret_cast<f2 (&)[D / 2]>(gx[2]);
-          f2 (&gS)[D / 2] = reinterpret_cast<f2 (&)[D / 2]>(gx[2 + D / 2]);
-          gx[0] = f2{0.f, 0.f}; gx[1] = f2{0.f, 0.f};
-          load_pairs<D>(A.adj, ar + 2, lane, macc);
+          f2 (&gS)[H / 2] = reinterpret_cast<f2 (&)[H / 2]>(gx[2 + D / 2]);
+          gx[0] = f2{0.f, 0.f}; gx[1] = f2{0.f, 0.f}; gx[XL - 1] = f2{0.f, 0.f};
+          load_pairs<D>(A.adj, ar + RM, lane, macc);
+          if constexpr (MULTI) {
 #pragma unroll
-          for (int j = 0; j < D / 2; ++j) gS[j] = f2{0.f, 0.f};
+            for (int j = 0; j < H / 2; ++j) gS[j] = f2{0.f, 0.f};
+          } else {
+            load_pairs<H>(A.adj, ar + 2, lane, gS);             // the single phi: summed over the three L nets across passes
+          }
           const int p0 = in_ptr[n], p1 = in_ptr[n + 1];
           {
-            f2 x[C::L_IN / 2];
-            f2 (&S)[D / 2] = reinterpret_cast<f2 (&)[D / 2]>(x[2 + D / 2]);
+            f2 x[XL];
+            f2 (&S)[H / 2] = reinterpret_cast<f2 (&)[H / 2]>(x[2 + D / 2]);
 #pragma unroll
-            for (int j = 0; j < D / 2; ++j) S[j] = f2{0.f, 0.f};
+            for (int j = 0; j < H / 2; ++j) S[j] = f2{0.f, 0.f};
 #ifdef GNS_ABLATE_MSGSUM
             for (int p = p0; p < p0; ++p) {
 #else
-            for (int p = p0; p < p1; ++p) {                     // message sum of family fphi (main.py:155-163)
+            for (int p = p0; p < p1; ++p) {                     // hidden-vector sum of family fphi (main.py:155-163, folded)
 #endif
-              f2 xe[(C::PHI_IN + 1) / 2], a1[H / 2], a2[H / 2], y[C::PHI_OUTP / 2];
+              f2 xe[(C::PHI_IN + 1) / 2], a1[H / 2], a2[H / 2];
               edge_input(p, m, xe);
-              mlp_fwd<C::PHI_IN, H, C::PHI_OUTP>(PT + A.t_off[fphi] + koff * A.t_sz[fphi], xe, a1, a2, y);
-              if constexpr (MULTI) {
+              mlp2_fwd<C::PHI_IN, H>(PT + A.t_off[fphi] + koff * A.t_sz[fphi], xe, a1, a2);
 #pragma unroll
-                for (int j = 0; j < D / 2; ++j) S[j] += y[j];
-              } else {
-                S[0].x += y[0].x;                               // [E,1] scattered into column 0 (main.py:170)
-              }
+              for (int j = 0; j < H / 2; ++j) S[j] += a2[j];
             }
             x[0] = f2{s0.x, s0.y}; x[1] = f2{s0.z, s0.w};
 #pragma unroll
             for (int i = 0; i < D / 2; ++i) x[2 + i] = m[i];
+            x[XL - 1] = f2{(float)(p1 - p0), 0.f};
             f2 a1[H / 2], a2[H / 2], y[OUTP / 2], g3[OUTP / 2], g2[H / 2], g1[H / 2];
-            mlp_fwd<C::L_IN, H, OUTP>(PT + A.t_off[C::NPHI + l] + koff * A.t_sz[C::NPHI + l], x, a1, a2, y);
+            mlp_fwd<C::LF_IN, H, OUTP>(PT + A.t_off[C::NPHI + l] + koff * A.t_sz[C::NPHI + l], x, a1, a2, y);
             if constexpr (l == 0) g3[0] = f2{a0.y, 0.f};                                  // theta += L_theta (main.py:182)
             else if constexpr (l == 1) g3[0] = f2{is_gen[n] ? 0.f : a0.x, 0.f};           // v moves only without a generator (main.py:184-186)
             else {
 #pragma unroll
               for (int j = 0; j < D / 2; ++j) g3[j] = macc[j];                            // m += L_m (main.py:188)
             }
-            mlp_bwd<C::L_IN, H, OUTP, C::L_IN, true>(PN + A.n_off[C::NPHI + l] + koff * A.n_sz[C::NPHI + l], a1, a2, g3, g2, g1, gx);
+            mlp_bwd<C::LF_IN, H, OUTP, 2 * XL, true>(PN + A.n_off[C::NPHI + l] + koff * A.n_sz[C::NPHI + l], a1, a2, g3, g2, g1, gx);
             xsum.x += gx[0].x; xsum.y += gx[0].y; xsum.z += gx[1].x;
-            if constexpr (!MULTI) xsum.w += gS[0].x;            // all three L nets read column 0 of the same message sum
-            dw_accumulate<C::L_IN, H, OUT, OUTP>(rec, lane, TL, accL, x, a1, a2, g1, g2, g3);
+            dw_accumulate<C::LF_IN, H, OUT, OUTP>(rec, lane, TL, accL, x, a1, a2, g1, g2, g3);
           }
           if constexpr (MULTI) {
 #ifdef GNS_ABLATE_MSGBWD
             for (int p = p0; p < p0; ++p) {
 #else
-            for (int p = p0; p < p1; ++p) {                     // back through the messages of the lines ending at n
+            for (int p = p0; p < p1; ++p) {                     // back through the hidden vectors of the lines ending at n
 #endif
-              f2 xe[(C::PHI_IN + 1) / 2], a1[H / 2], a2[H / 2], y[C::PHI_OUTP / 2], g2[H / 2], g1[H / 2];
+              f2 xe[(C::PHI_IN + 1) / 2], a1[H / 2], a2[H / 2], g2[H / 2], g1[H / 2];
               edge_input(p, m, xe);
-              mlp_fwd<C::PHI_IN, H, C::PHI_OUTP>(PT + A.t_off[fphi] + koff * A.t_sz[fphi], xe, a1, a2, y);
+              mlp2_fwd<C::PHI_IN, H>(PT + A.t_off[fphi] + koff * A.t_sz[fphi], xe, a1, a2);
               // x = [m(dst) | ...] (main.py:155): the m part of the input adjoint goes straight into macc
-              mlp_bwd<C::PHI_IN, H, C::PHI_OUTP, D, true>(PN + A.n_off[fphi] + koff * A.n_sz[fphi], a1, a2, gS, g2, g1, macc);
-              dw_accumulate<C::PHI_IN, H, C::PHI_OUT, C::PHI_OUTP>(rec, lane, TP, accP, xe, a1, a2, g1, g2, gS);
+              mlp2_bwd<C::PHI_IN, H, D, true>(PN + A.n_off[fphi] + koff * A.n_sz[fphi], a1, a2, gS, g2, g1, macc);
+              dw_accumulate2<C::PHI_IN, H>(rec, lane, TP, accP, xe, a1, g1, g2);
             }
+          } else {
+            store_pairs<H>(A.adj, ar + 2, lane, gS);
           }
           *row_ptr(A.adj, ar + 1, lane) = xsum;
-          store_pairs<D>(A.adj, ar + 2, lane, macc);
+          store_pairs<D>(A.adj, ar + RM, lane, macc);
         }
-        dw_flush<C::L_IN, H, OUT>(lane, TL, accL, slab + A.f_off[C::NPHI + l] + koff * A.f_sz[C::NPHI + l]);
-        if constexpr (MULTI) dw_flush<C::PHI_IN, H, C::PHI_OUT>(lane, TP, accP, slab + A.f_off[fphi] + koff * A.f_sz[fphi]);
+        dw_flush<C::LF_IN, H, OUT>(lane, TL, accL, slab + A.g_off[C::NPHI + l] + koff * A.g_sz[C::NPHI + l]);
+        if constexpr (MULTI) dw_flush2<C::PHI_IN, H>(lane, TP, accP, slab + A.g_off[fphi] + koff * A.g_sz[fphi]);
         STAMP(5 + l)
       });
-      if constexpr (!MULTI) {                                  // the single phi: its output adjoint is the sum over the three L nets
-        const DwTile TP = dw_tile<C::PHI_IN, H, C::PHI_OUT>(lane);
+      if constexpr (!MULTI) {                                  // the single phi: its hidden-sum adjoint is the sum over the three L nets
+        const DwTile TP = dw_tile2<C::PHI_IN, H>(lane);
         f2 accP[4][2];
         zero_acc(accP);
         for (int n = n0; n < n1; ++n) {
           const long long ar = adj_row(n), rr = state_row(k, n);
-          const f4 xsum = *row_ptr(A.adj, ar + 1, lane);
-          f2 m[D / 2], macc[D / 2], gS[1];
+          f2 m[D / 2], macc[D / 2], gS[H / 2];
           load_pairs<D>(A.state, rr + 1, lane, m);
-          load_pairs<D>(A.adj, ar + 2, lane, macc);
-          gS[0] = f2{xsum.w, 0.f};
+          load_pairs<D>(A.adj, ar + RM, lane, macc);
+          load_pairs<H>(A.adj, ar + 2, lane, gS);
           const int p0 = in_ptr[n], p1 = in_ptr[n + 1];
           for (int p = p0; p < p1; ++p) {
-            f2 x[(C::PHI_IN + 1) / 2], a1[H / 2], a2[H / 2], y[1], g2[H / 2], g1[H / 2];
-            edge_input(p, m, x);
-            mlp_fwd<C::PHI_IN, H, 2>(PT + A.t_off[0] + koff * A.t_sz[0], x, a1, a2, y);
-            mlp_bwd<C::PHI_IN, H, 2, D, true>(PN + A.n_off[0] + koff * A.n_sz[0], a1, a2, gS, g2, g1, macc);
-            dw_accumulate<C::PHI_IN, H, 1, 2>(rec, lane, TP, accP, x, a1, a2, g1, g2, gS);
+            f2 xe[(C::PHI_IN + 1) / 2], a1[H / 2], a2[H / 2], g2[H / 2], g1[H / 2];
+            edge_input(p, m, xe);
+            mlp2_fwd<C::PHI_IN, H>(PT + A.t_off[0] + koff * A.t_sz[0], xe, a1, a2);
+            mlp2_bwd<C::PHI_IN, H, D, true>(PN + A.n_off[0] + koff * A.n_sz[0], a1, a2, gS, g2, g1, macc);
+            dw_accumulate2<C::PHI_IN, H>(rec, lane, TP, accP, xe, a1, g1, g2);
           }
-          store_pairs<D>(A.adj, ar + 2, lane, macc);
+          store_pairs<D>(A.adj, ar + RM, lane, macc);
         }
-        dw_flush<C::PHI_IN, H, 1>(lane, TP, accP, slab + A.f_off[0] + koff * A.f_sz[0]);
+        dw_flush2<C::PHI_IN, H>(lane, TP, accP, slab + A.g_off[0] + koff * A.g_sz[0]);
       }
       // ---------------- finalize: (vbar, thbar)_k = identity path + input adjoints; dpbar_k for the next Pb-0 -----------
       for (int n = n0; n < n1; ++n) {
         const long long ar = adj_row(n);
         const f4 a0 = *row_ptr(A.adj, ar, lane), xsum = *row_ptr(A.adj, ar + 1, lane);
         *row_ptr(A.adj, ar, lane) = f4{a0.x + xsum.x, a0.y + xsum.y, xsum.z, 0.f};     // main.py:182,186 identity paths
-        *row_ptr(A.adj, ar + 1, lane) = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 1 + RHB; ++q) *row_ptr(A.adj, ar + 1 + q, lane) = f4{0.f, 0.f, 0.f, 0.f};
       }
       STAMP(8)
     }
@@ -473,12 +574,61 @@ __global__ void gns_reduce_stage1(const float* __restrict__ slab, float* __restr
   for (long long s = s0; s < s1; ++s) acc += slab[s * sf + i];
   part[j * sf + i] = acc;
 }
-__global__ void gns_reduce_stage2(const float* __restrict__ part, float* __restrict__ grad, long long sf, long long nparam) {
+__global__ void gns_reduce_stage2(const float* __restrict__ part, float* __restrict__ out, long long sf, long long n) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nparam) return;
+  if (i >= n) return;
   float acc = 0.f;
   for (int j = 0; j < GNS_RED_PARTS; ++j) acc += part[j * sf + i];
-  grad[i] += acc;
+  out[i] = acc;
+}
+
+// Folded gradients -> gradients of the reference's parameters (gns_common.h, "FOLDED form"):
+//   C = A W4, c0 = A b4 with A = W1L[:, 4+d:]  =>  dA = dC W4^T + dc0 b4^T,  dW4 = sum_L A^T dC,  db4 = sum_L A^T dc0.
+// One block per (family, k); a phi block also collects dW4/db4 from every L family that reads it, in a fixed order.
+__global__ void gns_unfold_kernel(const float* __restrict__ gf, const float* __restrict__ flat, float* __restrict__ grad,
+                                  GnsFamilies fam, int K, int D, int H) {
+  const int blk = blockIdx.x, f = blk / K, k = blk % K;
+  const bool is_phi = f < fam.nphi;
+  const int IN = fam.in[f], OUT = fam.out[f];
+  const int HEAD = 4 + D, INF = HEAD + H + 1;
+  const float* g = gf + fam.g_off[f] + (int64_t)k * fam.g_sz[f];
+  float* dst = grad + fam.flat_off[f] + (int64_t)k * fam.flat_sz[f];
+  if (is_phi) {
+    const int n12 = IN * H + H + H * H + H;                       // W1 b1 W2 b2 sit at the same offsets in both layouts
+    for (int e = threadIdx.x; e < n12; e += blockDim.x) dst[e] += g[e];
+    float* dW4 = dst + n12;                                       // [OUT][H]
+    float* db4 = dW4 + OUT * H;
+    for (int e = threadIdx.x; e < OUT * H + OUT; e += blockDim.x) {
+      float acc = 0.f;
+      for (int lf = fam.nphi; lf < fam.nfam; ++lf) {
+        if (fam.phi_of[lf] != f) continue;
+        const float* gl = gf + fam.g_off[lf] + (int64_t)k * fam.g_sz[lf];             // dW1'[H][INF]
+        const float* Wl = flat + fam.flat_off[lf] + (int64_t)k * fam.flat_sz[lf];     // W1L [H][L_IN]
+        const int LIN = fam.in[lf];
+        if (e < OUT * H) { const int q = e / H, j = e % H; for (int c = 0; c < H; ++c) acc += Wl[c * LIN + HEAD + q] * gl[c * INF + HEAD + j]; }
+        else { const int q = e - OUT * H; for (int c = 0; c < H; ++c) acc += Wl[c * LIN + HEAD + q] * gl[c * INF + HEAD + H]; }
+      }
+      if (e < OUT * H) dW4[e] += acc; else db4[e - OUT * H] += acc;
+    }
+    return;
+  }
+  const int fp = fam.phi_of[f], PO = fam.out[fp];
+  const float* ps = flat + fam.flat_off[fp] + (int64_t)k * fam.flat_sz[fp];
+  const float* pW4 = ps + fam.in[fp] * H + H + H * H + H;
+  const float* pb4 = pW4 + PO * H;
+  for (int e = threadIdx.x; e < H * IN; e += blockDim.x) {        // dW1L [H][IN]
+    const int c = e / IN, i = e % IN;
+    float v = 0.f;
+    if (i < HEAD) v = g[c * INF + i];
+    else if (i - HEAD < PO) {
+      const int q = i - HEAD;
+      for (int j = 0; j < H; ++j) v += g[c * INF + HEAD + j] * pW4[q * H + j];
+      v += g[c * INF + HEAD + H] * pb4[q];
+    }                                                             // single phi: columns 4+d+1.. multiply zeros -> gradient 0
+    dst[e] += v;
+  }
+  const int rest = H + H * H + H + OUT * H + OUT;                 // b1 W2 b2 W4 b4
+  for (int e = threadIdx.x; e < rest; e += blockDim.x) dst[H * IN + e] += g[H * INF + e];
 }
 
 template <int D, int H, bool MULTI>
@@ -496,8 +646,10 @@ int gns_launch_backward(int d, int h, int multi, const GnsBwdArgs& A, int blocks
   return GNS_EUNSUPPORTED;
 }
 
-int gns_launch_reduce(const float* slab, float* part, float* grad, long long nslab, long long sf, long long nparam, hipStream_t st) {
+int gns_launch_reduce(const float* slab, float* part, float* tmp, const float* flat, float* grad, long long nslab, long long sf,
+                      const GnsFamilies& fam, int K, int D, int H, hipStream_t st) {
   hipLaunchKernelGGL(gns_reduce_stage1, dim3((unsigned)((sf + 255) / 256), GNS_RED_PARTS), dim3(256), 0, st, slab, part, nslab, sf);
-  hipLaunchKernelGGL(gns_reduce_stage2, dim3((unsigned)((nparam + 255) / 256)), dim3(256), 0, st, part, grad, sf, nparam);
+  hipLaunchKernelGGL(gns_reduce_stage2, dim3((unsigned)((fam.g_total + 255) / 256)), dim3(256), 0, st, part, tmp, sf, (long long)fam.g_total);
+  hipLaunchKernelGGL(gns_unfold_kernel, dim3(fam.nfam * K), dim3(256), 0, st, tmp, flat, grad, fam, K, D, H);
   return hipGetLastError() == hipSuccess ? GNS_OK : GNS_ELAUNCH;
 }

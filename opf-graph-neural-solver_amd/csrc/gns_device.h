@@ -159,6 +159,71 @@ __device__ __forceinline__ void mlp_bwd(cfp blk, const f2 (&a1)[H / 2], const f2
   pin_all(gx);
 }
 
+// ---- phi' : the first two layers of a LearningBlock (the third is folded into L', see gns_common.h) --------------
+// T-stream: W1t[IN][H] b1[H] W2t[H][H] b2[H]
+template <int IN, int H>
+struct TLay2 {
+  static constexpr int ob1 = IN * H, oW2 = ob1 + H, ob2 = oW2 + H * H, total = ob2 + H;
+};
+
+template <int IN, int H>
+__device__ __forceinline__ void mlp2_fwd(cfp blk, const f2 (&x)[(IN + 1) / 2], f2 (&a1)[H / 2], f2 (&a2)[H / 2]) {
+  using B = TLay2<IN, H>;
+  stream_pairs<B::total>(blk, [&](auto w_, f2 s) {
+    constexpr int w = decltype(w_)::value;
+    if constexpr (w < B::ob1) {
+      constexpr int i = w / H, j = (w % H) / 2;
+      const f2 xi = splat(lane_of<i>(x));
+      a1[j] = (i == 0) ? s * xi : __builtin_elementwise_fma(s, xi, a1[j]);
+    } else if constexpr (w < B::oW2) {
+      constexpr int j = (w - B::ob1) / 2;
+      a1[j] = lrelu2(a1[j] + s);
+    } else if constexpr (w < B::ob2) {
+      constexpr int q = w - B::oW2, i = q / H, j = (q % H) / 2;
+      const f2 xi = splat(lane_of<i>(a1));
+      a2[j] = (i == 0) ? s * xi : __builtin_elementwise_fma(s, xi, a2[j]);
+    } else {
+      constexpr int j = (w - B::ob2) / 2;
+      a2[j] = lrelu2(a2[j] + s);
+    }
+  });
+  pin_all(a2);
+}
+
+// N-stream: W2n[H][H] W1n[H][INP].  gh = dL/d(a2) (post-activation).  g2, g1 = pre-activation adjoints, gx = dL/dx[0..NX).
+template <int IN, int H>
+struct NLay2 {
+  static constexpr int INP = IN + (IN & 1);
+  static constexpr int oW1 = H * H, total = oW1 + H * INP;
+};
+
+template <int IN, int H, int NX, bool ACC = false>
+__device__ __forceinline__ void mlp2_bwd(cfp blk, const f2 (&a1)[H / 2], const f2 (&a2)[H / 2], const f2 (&gh)[H / 2],
+                                         f2 (&g2)[H / 2], f2 (&g1)[H / 2], f2 (&gx)[NX / 2]) {
+  using B = NLay2<IN, H>;
+  static_assert(NX % 2 == 0 && NX <= B::INP, "NX");
+#pragma unroll
+  for (int u = 0; u < H / 2; ++u) g2[u] = gh[u] * dlrelu2(a2[u]);
+  stream_pairs<B::total>(blk, [&](auto w_, f2 s) {
+    constexpr int w = decltype(w_)::value;
+    if constexpr (w < B::oW1) {
+      constexpr int j = w / H, i = (w % H) / 2;
+      const f2 gj = splat(lane_of<j>(g2));
+      g1[i] = (j == 0) ? s * gj : __builtin_elementwise_fma(s, gj, g1[i]);
+    } else {
+      constexpr int q = w - B::oW1, j = q / B::INP, i = (q % B::INP) / 2;
+      if constexpr (q == 0) {
+        static_for<0, H / 2>([&](auto u_) { constexpr int u = decltype(u_)::value; g1[u] = g1[u] * dlrelu2(a1[u]); });
+      }
+      if constexpr (2 * i < NX) {
+        const f2 gj = splat(lane_of<j>(g1));
+        gx[i] = (j == 0 && !ACC) ? s * gj : __builtin_elementwise_fma(s, gj, gx[i]);
+      }
+    }
+  });
+  pin_all(gx);
+}
+
 // float4-row addressing: [row][lane] with 16 B per lane -> every wave access is one contiguous 1 KiB
 __device__ __forceinline__ const f4* row_ptr(const float* base, long long row, int lane) {
   return reinterpret_cast<const f4*>(base) + row * GNS_LANES + lane;

@@ -4,20 +4,58 @@
 #include "gns_kernels.h"
 
 // ------------------------------------------------------------------------------------------------
-// pack_params: flat state_dict-order parameters -> T-stream (forward) and N-stream (backward) blocks
+// pack_params: flat state_dict-order parameters -> folded T-stream (forward) and N-stream (backward) blocks
+// (gns_common.h: phi' = first two layers of phi; L' = L with the phi output layer folded into its first layer)
 // ------------------------------------------------------------------------------------------------
 __global__ void gns_pack_params_kernel(const float* __restrict__ flat, float* __restrict__ pt, float* __restrict__ pn,
-                                       GnsFamilies fam, int K, int H) {
+                                       GnsFamilies fam, int K, int D, int H) {
   const int blk = blockIdx.x;            // (family, k)
   const int f = blk / K, k = blk % K;
-  const int IN = fam.in[f], OUT = fam.out[f], OUTP = OUT + (OUT & 1), INP = IN + (IN & 1);
+  const bool is_phi = f < fam.nphi;
+  const int IN = fam.in[f], OUT = fam.out[f], OUTP = OUT + (OUT & 1);
   const float* src = flat + fam.flat_off[f] + (int64_t)k * fam.flat_sz[f];
   const int sW1 = 0, sb1 = IN * H, sW2 = sb1 + H, sb2 = sW2 + H * H, sW4 = sb2 + H, sb4 = sW4 + OUT * H;
   float* t = pt + fam.t_off[f] + (int64_t)k * fam.t_sz[f];
-  const int ob1 = IN * H, oW2 = ob1 + H, ob2 = oW2 + H * H, oW4 = ob2 + H, ob4 = oW4 + H * OUTP, tt = ob4 + OUTP;
+  float* n = pn + fam.n_off[f] + (int64_t)k * fam.n_sz[f];
+  if (is_phi) {
+    const int INP = IN + (IN & 1);
+    const int ob1 = IN * H, oW2 = ob1 + H, ob2 = oW2 + H * H, tt = ob2 + H;
+    for (int e = threadIdx.x; e < (int)fam.t_sz[f]; e += blockDim.x) {
+      float v = 0.f;
+      if (e < ob1) { int i = e / H, j = e % H; v = src[sW1 + j * IN + i]; }
+      else if (e < oW2) v = src[sb1 + (e - ob1)];
+      else if (e < ob2) { int q = e - oW2, i = q / H, j = q % H; v = src[sW2 + j * H + i]; }
+      else if (e < tt) v = src[sb2 + (e - ob2)];
+      t[e] = v;
+    }
+    const int nW1 = H * H, nt = nW1 + H * INP;
+    for (int e = threadIdx.x; e < (int)fam.n_sz[f]; e += blockDim.x) {
+      float v = 0.f;
+      if (e < nW1) v = src[sW2 + e];
+      else if (e < nt) { int q = e - nW1, j = q / INP, i = q % INP; v = i < IN ? src[sW1 + j * IN + i] : 0.f; }
+      n[e] = v;
+    }
+    return;
+  }
+  // L family: input of the folded first layer = [v theta dp dq | m (D) | sum_e h_e (H) | deg]
+  const int fp = fam.phi_of[f];
+  const int PO = fam.out[fp];                                   // phi output width: D (multi) or 1
+  const float* ps = flat + fam.flat_off[fp] + (int64_t)k * fam.flat_sz[fp];
+  const int PIN = fam.in[fp];
+  const float* pW4 = ps + PIN * H + H + H * H + H;              // phi linear4.weight [PO][H]
+  const float* pb4 = pW4 + PO * H;                              // phi linear4.bias  [PO]
+  const int HEAD = 4 + D, INF = HEAD + H + 1, INFP = INF + (INF & 1);
+  auto w1f = [&](int c, int i) -> float {                       // folded first-layer weight W1'[c][i]
+    if (i < HEAD) return src[sW1 + c * IN + i];
+    float acc = 0.f;
+    if (i < HEAD + H) { const int j = i - HEAD; for (int q = 0; q < PO; ++q) acc += src[sW1 + c * IN + HEAD + q] * pW4[q * H + j]; }
+    else if (i == HEAD + H) { for (int q = 0; q < PO; ++q) acc += src[sW1 + c * IN + HEAD + q] * pb4[q]; }
+    return acc;
+  };
+  const int ob1 = INF * H, oW2 = ob1 + H, ob2 = oW2 + H * H, oW4 = ob2 + H, ob4 = oW4 + H * OUTP, tt = ob4 + OUTP;
   for (int e = threadIdx.x; e < (int)fam.t_sz[f]; e += blockDim.x) {
     float v = 0.f;
-    if (e < ob1) { int i = e / H, j = e % H; v = src[sW1 + j * IN + i]; }
+    if (e < ob1) { int i = e / H, j = e % H; v = w1f(j, i); }
     else if (e < oW2) v = src[sb1 + (e - ob1)];
     else if (e < ob2) { int q = e - oW2, i = q / H, j = q % H; v = src[sW2 + j * H + i]; }
     else if (e < oW4) v = src[sb2 + (e - ob2)];
@@ -25,13 +63,12 @@ __global__ void gns_pack_params_kernel(const float* __restrict__ flat, float* __
     else if (e < tt) { int j = e - ob4; v = j < OUT ? src[sb4 + j] : 0.f; }
     t[e] = v;
   }
-  float* n = pn + fam.n_off[f] + (int64_t)k * fam.n_sz[f];
-  const int nW2 = OUTP * H, nW1 = nW2 + H * H, nt = nW1 + H * INP;
+  const int nW2 = OUTP * H, nW1 = nW2 + H * H, nt = nW1 + H * INFP;
   for (int e = threadIdx.x; e < (int)fam.n_sz[f]; e += blockDim.x) {
     float v = 0.f;
     if (e < nW2) { int j = e / H, i = e % H; v = j < OUT ? src[sW4 + j * H + i] : 0.f; }
-    else if (e < nW1) { int q = e - nW2; v = src[sW2 + q]; }
-    else if (e < nt) { int q = e - nW1, j = q / INP, i = q % INP; v = i < IN ? src[sW1 + j * IN + i] : 0.f; }
+    else if (e < nW1) v = src[sW2 + (e - nW2)];
+    else if (e < nt) { int q = e - nW1, j = q / INFP, i = q % INFP; v = i < INF ? w1f(j, i) : 0.f; }
     n[e] = v;
   }
 }
@@ -149,21 +186,22 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
       const int p0 = in_ptr[n], p1 = in_ptr[n + 1];
       float upd_theta, upd_v;
       f2 upd_m[D / 2];
-      f2 S[C::PHI_OUTP / 2];        // message sum of the family in flight (one family at a time: fewer live registers)
-      auto message_sum = [&](auto f_) {                // sum over the lines ending at n of phi_f([m | r x b tau shift])  (main.py:155-163)
+      f2 S[H / 2];                  // sum over the lines ending at n of the hidden vector of phi' (one family at a time)
+      const float degf = (float)(p1 - p0);
+      auto message_sum = [&](auto f_) {                // main.py:155-163 with the output layer of phi folded into L'
         constexpr int f = decltype(f_)::value;
 #pragma unroll
-        for (int j = 0; j < C::PHI_OUTP / 2; ++j) S[j] = f2{0.f, 0.f};
+        for (int j = 0; j < H / 2; ++j) S[j] = f2{0.f, 0.f};
         for (int p = p0; p < p1; ++p) {
           const f4 e0 = *row_ptr(IN, row_ein + 3LL * p, lane), e1 = *row_ptr(IN, row_ein + 3LL * p + 1, lane);
           f2 x[(C::PHI_IN + 1) / 2];
 #pragma unroll
           for (int i = 0; i < D / 2; ++i) x[i] = m[i];
           x[D / 2] = f2{e0.x, e0.y}; x[D / 2 + 1] = f2{e0.z, e0.w}; x[D / 2 + 2] = f2{e1.x, 0.f};
-          f2 a1[H / 2], a2[H / 2], y[C::PHI_OUTP / 2];
-          mlp_fwd<C::PHI_IN, H, C::PHI_OUTP>(PT + A.t_off[f] + koff * A.t_sz[f], x, a1, a2, y);
+          f2 a1[H / 2], a2[H / 2];
+          mlp2_fwd<C::PHI_IN, H>(PT + A.t_off[f] + koff * A.t_sz[f], x, a1, a2);
 #pragma unroll
-          for (int j = 0; j < C::PHI_OUTP / 2; ++j) S[j] += y[j];
+          for (int j = 0; j < H / 2; ++j) S[j] += a2[j];
         }
       };
       if constexpr (!MULTI) message_sum(std::integral_constant<int, 0>{});
@@ -171,22 +209,20 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
         constexpr int l = decltype(l_)::value;
         constexpr int fphi = MULTI ? (l == 0 ? 1 : (l == 1 ? 0 : 2)) : 0;   // phi_theta, phi_v, phi_m
         if constexpr (MULTI) message_sum(std::integral_constant<int, fphi>{});
-        f2 x[C::L_IN / 2];
+        f2 x[(C::LF_IN + 1) / 2];                      // [v theta | dp dq | m | sum h | deg]
         x[0] = f2{s0.x, s0.y}; x[1] = f2{s0.z, s0.w};
 #pragma unroll
         for (int i = 0; i < D / 2; ++i) x[2 + i] = m[i];
 #pragma unroll
-        for (int i = 0; i < D / 2; ++i) {
-          if constexpr (MULTI) x[2 + D / 2 + i] = S[i];
-          else x[2 + D / 2 + i] = (i == 0) ? f2{S[0].x, 0.f} : f2{0.f, 0.f};   // [E,1] scattered into column 0 (main.py:170)
-        }
+        for (int i = 0; i < H / 2; ++i) x[2 + D / 2 + i] = S[i];
+        x[2 + D / 2 + H / 2] = f2{degf, 0.f};
         f2 a1[H / 2], a2[H / 2];
         if constexpr (l < 2) {
           f2 y[1];
-          mlp_fwd<C::L_IN, H, 2>(PT + A.t_off[C::NPHI + l] + koff * A.t_sz[C::NPHI + l], x, a1, a2, y);
+          mlp_fwd<C::LF_IN, H, 2>(PT + A.t_off[C::NPHI + l] + koff * A.t_sz[C::NPHI + l], x, a1, a2, y);
           if constexpr (l == 0) upd_theta = y[0].x; else upd_v = y[0].x;
         } else {
-          mlp_fwd<C::L_IN, H, D>(PT + A.t_off[C::NPHI + 2] + koff * A.t_sz[C::NPHI + 2], x, a1, a2, upd_m);
+          mlp_fwd<C::LF_IN, H, D>(PT + A.t_off[C::NPHI + 2] + koff * A.t_sz[C::NPHI + 2], x, a1, a2, upd_m);
         }
       });
       const float th_new = s0.y + upd_theta;                          // main.py:182
@@ -316,8 +352,8 @@ int gns_launch_forward(int d, int h, int multi, const GnsFwdArgs& A, int threads
   return GNS_EUNSUPPORTED;
 }
 
-int gns_launch_pack_params(const float* flat, float* pt, float* pn, const GnsFamilies& fam, int K, int H, hipStream_t st) {
-  hipLaunchKernelGGL(gns_pack_params_kernel, dim3(fam.nfam * K), dim3(256), 0, st, flat, pt, pn, fam, K, H);
+int gns_launch_pack_params(const float* flat, float* pt, float* pn, const GnsFamilies& fam, int K, int D, int H, hipStream_t st) {
+  hipLaunchKernelGGL(gns_pack_params_kernel, dim3(fam.nfam * K), dim3(256), 0, st, flat, pt, pn, fam, K, D, H);
   return hipGetLastError() == hipSuccess ? GNS_OK : GNS_ELAUNCH;
 }
 

@@ -18,7 +18,9 @@ struct GnsDims {
   static constexpr int PHI_IN = D + 5;                 // [m(dst) | r x b tau shift]        main.py:155
   static constexpr int PHI_OUT = MULTI ? D : 1;        // main.py:126-130
   static constexpr int PHI_OUTP = PHI_OUT + (PHI_OUT & 1);
-  static constexpr int L_IN = 4 + 2 * D;               // [v theta dp dq | m | phi_sum]      main.py:165-171
+  static constexpr int L_IN = 4 + 2 * D;               // [v theta dp dq | m | phi_sum]      main.py:165-171 (flat layout)
+  static constexpr int LF_IN = 4 + D + H + 1;          // folded: [v theta dp dq | m | sum_e h_e | deg]
+  static constexpr int HQ = (H + 3) / 4;               // float4 rows of a hidden vector
   static constexpr int MQ = (D + 3) / 4;               // float4 rows of the latent vector
   static constexpr int RB = 1 + MQ;                    // state rows per bus: (v,theta,dp,dq) + m
 };
@@ -46,15 +48,16 @@ struct GnsBwdArgs {
   float* adj;                            // [G][N][RB][64] float4: (vbar, thbar, dpbar, -) + mbar
   float* slots;                          // [G][6][E][64] per-line physics adjoints
   float* slab;                           // [blocks*8][slab_floats] per-wave weight-gradient accumulators
-  long long t_off[6], t_sz[6], n_off[6], n_sz[6], f_off[6], f_sz[6];
+  long long t_off[6], t_sz[6], n_off[6], n_sz[6], g_off[6], g_sz[6];
   float gw[GNS_MAX_K];
   long long Bt, G, slab_floats;
   int N, E, K, part_idx;
 };
 
 int gns_launch_backward(int d, int h, int multi, const GnsBwdArgs& A, int blocks, hipStream_t st);
-int gns_launch_reduce(const float* slab, float* part, float* grad, long long nslab, long long sf, long long nparam, hipStream_t st);
+int gns_launch_reduce(const float* slab, float* part, float* tmp, const float* flat, float* grad, long long nslab, long long sf,
+                      const GnsFamilies& fam, int K, int D, int H, hipStream_t st);
 int gns_launch_forward(int d, int h, int multi, const GnsFwdArgs& A, int threads, hipStream_t st);
-int gns_launch_pack_params(const float* flat, float* pt, float* pn, const GnsFamilies& fam, int K, int H, hipStream_t st);
+int gns_launch_pack_params(const float* flat, float* pt, float* pn, const GnsFamilies& fam, int K, int D, int H, hipStream_t st);
 int gns_launch_pack_inputs(const int* topo, const float* buses, const float* lines, const float* gens, float* out, int N,
                            int E, int Gn, long long Bt, long long groups, hipStream_t st);
