@@ -169,13 +169,18 @@ __device__ __forceinline__ void dw_accumulate(float* rec, int lane, const DwTile
   }
 }
 
+// phi' needs only 30 tiles, so the two half-waves take the same tiles and sweep one half of the 64 records each:
+// all 64 lanes write their record at once (no masked halves) and the sweep is 32 rows instead of 64.
 template <int IN, int H>
 __device__ __forceinline__ DwTile dw_tile2(int lane) {
   using R = RecLay2<IN, H>;
+  static_assert(R::NT <= 32, "two half-waves share the tile set");
   DwTile T;
-  int t = lane < R::NT ? lane : 0;
+  int t = (lane & 31) < R::NT ? (lane & 31) : 0;
   if (t < R::T1) { T.kind = 0; T.cb = t / R::TX; T.ib = t % R::TX; T.woff = R::oG1 + 4 * T.cb; T.uoff = R::oX + 4 * T.ib; }
   else { t -= R::T1; T.kind = 1; T.cb = t / R::TH; T.ib = t % R::TH; T.woff = R::oG2 + 4 * T.cb; T.uoff = R::oA1 + 4 * T.ib; }
+  const int half_off = (lane >> 5) * GNS_REC_ROWS * R::RS;      // rows 32..63 for the upper half-wave
+  T.woff += half_off; T.uoff += half_off;
   return T;
 }
 
@@ -187,23 +192,28 @@ __device__ __forceinline__ void dw_accumulate2(float* rec, int lane, const DwTil
   asm volatile("" :: "v"(x[0]), "v"(a1[0]), "v"(g1[0]), "v"(g2[0]));
   return;
 #endif
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
 #ifndef GNS_ABLATE_RECWRITE
-    if ((lane >> 5) == half) rec_write2<IN, H>(rec, lane & 31, x, a1, g1, g2);
+  rec_write2<IN, H>(rec, lane, x, a1, g1, g2);
 #endif
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    dw_sweep<R::RS>(rec, T, acc);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  dw_sweep<R::RS>(rec, T, acc);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
 }
 
 // phi' tile -> folded-gradient block W1[H][IN] b1[H] W2[H][H] b2[H]
 template <int IN, int H>
 __device__ __forceinline__ void dw_flush2(int lane, const DwTile& T, const f2 (&acc)[4][2], float* slab_blk) {
   using R = RecLay2<IN, H>;
+  float tot[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int bq = 0; bq < 4; ++bq) {
+      const float v = (bq & 1) ? acc[a][bq >> 1].y : acc[a][bq >> 1].x;
+      tot[a][bq] = v + __shfl_xor(v, 32);                        // rows 0..31 + rows 32..63
+    }
   if (lane < R::NT) {
     constexpr int ob1 = IN * H, oW2 = ob1 + H, ob2 = oW2 + H * H;
 #pragma unroll
@@ -212,7 +222,7 @@ __device__ __forceinline__ void dw_flush2(int lane, const DwTile& T, const f2 (&
 #pragma unroll
       for (int bq = 0; bq < 4; ++bq) {
         const int i = 4 * T.ib + bq;
-        const float val = (bq & 1) ? acc[a][bq >> 1].y : acc[a][bq >> 1].x;
+        const float val = tot[a][bq];
         int idx = -1;
         if (T.kind == 0) { if (c < H) idx = (i < IN) ? c * IN + i : (i == IN ? ob1 + c : -1); }
         else { if (c < H) idx = (i < H) ? oW2 + c * H + i : (i == H ? ob2 + c : -1); }
@@ -272,8 +282,8 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
   const long long R = gns_in_rows(N, E);
   const float* IN = A.in;
 
-  constexpr int RECF = GNS_REC_ROWS * gns_cmax(gns_cmax(RecLay<C::LF_IN, H, D>::RS, RecLay<C::LF_IN, H, 1>::RS),
-                                                 RecLay2<C::PHI_IN, H>::RS);
+  constexpr int RECF = gns_cmax(GNS_REC_ROWS * gns_cmax(RecLay<C::LF_IN, H, D>::RS, RecLay<C::LF_IN, H, 1>::RS),
+                                2 * GNS_REC_ROWS * RecLay2<C::PHI_IN, H>::RS);
   __shared__ __attribute__((aligned(16))) float rec_all[W][RECF];
   __shared__ float red[2][W][GNS_LANES];
   float* rec = rec_all[wave];
