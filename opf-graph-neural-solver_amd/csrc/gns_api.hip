@@ -120,7 +120,7 @@ extern "C" int gns_forward(const gns_config* cfg, const void* topo_dev, const fl
   GnsFwdArgs A;
   std::memset(&A, 0, sizeof(A));
   A.topo = (const int*)topo_dev; A.pt = pt; A.in = pin;
-  A.state = (float*)(ws + L.off_state); A.lam = (float*)(ws + L.off_lam);
+  A.state = (float*)(ws + L.off_state); A.lam = (float*)(ws + L.off_lam); A.msg = (float*)(ws + L.off_msg);
   A.v_out = v; A.theta_out = theta; A.total_out = total_loss; A.last_out = last_loss;
   for (int i = 0; i < fam.nfam; ++i) { A.t_off[i] = fam.t_off[i]; A.t_sz[i] = fam.t_sz[i]; }
   for (int k = 0; k < K; ++k) A.gw[k] = (float)std::pow((double)cfg->gamma, (double)(K - k));   // main.py:198
@@ -159,7 +159,7 @@ extern "C" int gns_backward(const gns_config* cfg, const void* topo_dev, const f
   std::memset(&A, 0, sizeof(A));
   A.topo = (const int*)topo_dev;
   A.pt = (const float*)(fw + L.off_pt); A.pn = (const float*)(fw + L.off_pn); A.in = (const float*)(fw + L.off_in);
-  A.state = (const float*)(fw + L.off_state); A.lam = (const float*)(fw + L.off_lam);
+  A.state = (const float*)(fw + L.off_state); A.lam = (const float*)(fw + L.off_lam); A.msg = (const float*)(fw + L.off_msg);
   A.g_total = grad_total; A.g_last = grad_last; A.g_v = grad_v; A.g_theta = grad_theta;
   A.adj = (float*)(bw + B.off_adj); A.slots = (float*)(bw + B.off_slots); A.slab = (float*)(bw + B.off_slab);
   for (int i = 0; i < fam.nfam; ++i) {

@@ -484,19 +484,8 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
           {
             f2 x[XL];
             f2 (&S)[H / 2] = reinterpret_cast<f2 (&)[H / 2]>(x[2 + D / 2]);
-#pragma unroll
-            for (int j = 0; j < H / 2; ++j) S[j] = f2{0.f, 0.f};
-#ifdef GNS_ABLATE_MSGSUM
-            for (int p = p0; p < p0; ++p) {
-#else
-            for (int p = p0; p < p1; ++p) {                     // hidden-vector sum of family fphi (main.py:155-163, folded)
-#endif
-              f2 xe[(C::PHI_IN + 1) / 2], a1[H / 2], a2[H / 2];
-              edge_input(p, m, xe);
-              mlp2_fwd<C::PHI_IN, H>(PT + A.t_off[fphi] + koff * A.t_sz[fphi], xe, a1, a2);
-#pragma unroll
-              for (int j = 0; j < H / 2; ++j) S[j] += a2[j];
-            }
+            // the hidden-vector sum of family fphi (main.py:155-163, folded) was saved by the forward pass
+            load_pairs<H>(A.msg, ((((long long)k * A.G + g) * N + n) * C::NPHI + fphi) * C::HQ, lane, S);
             x[0] = f2{s0.x, s0.y}; x[1] = f2{s0.z, s0.w};
 #pragma unroll
             for (int i = 0; i < D / 2; ++i) x[2 + i] = m[i];

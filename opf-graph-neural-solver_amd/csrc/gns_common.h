@@ -123,7 +123,7 @@ struct GnsFwdLayout {
   int64_t mq;            // float4 rows holding the latent vector: ceil(d/4)
   int64_t rows_bus;      // 1 + mq
   int64_t slots;         // K+1 when the state is saved for backward, else 1
-  size_t off_pt, off_pn, off_in, off_lam, off_state, total;
+  size_t off_pt, off_pn, off_in, off_lam, off_state, off_msg, total;
 };
 
 static inline size_t gns_align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -140,6 +140,8 @@ static inline void gns_fwd_layout(int N, int E, int d, int h, int K, int multi, 
   L->off_in = o;    o = gns_align256(o + (size_t)L->groups * gns_in_rows(N, E) * GNS_LANES * 16);
   L->off_lam = o;   o = gns_align256(o + (size_t)K * L->groups * GNS_LANES * 8);
   L->off_state = o; o = gns_align256(o + (size_t)L->slots * L->groups * N * L->rows_bus * GNS_LANES * 16);
+  // hidden-vector sums per (step, bus, phi family): saved by the training forward so that the backward need not recompute them
+  L->off_msg = o;   o = gns_align256(o + (save ? (size_t)K * L->groups * N * (multi ? 3 : 1) * ((h + 3) / 4) * GNS_LANES * 16 : 0));
   L->total = o;
 }
 

@@ -203,6 +203,7 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
 #pragma unroll
           for (int j = 0; j < H / 2; ++j) S[j] += a2[j];
         }
+        if (A.save) store_pairs<H>(A.msg, ((((long long)k * A.G + g) * N + n) * C::NPHI + f) * C::HQ, lane, S);
       };
       if constexpr (!MULTI) message_sum(std::integral_constant<int, 0>{});
       static_for<0, 3>([&](auto l_) {                  // l: 0 = L_theta, 1 = L_v, 2 = L_m   (main.py:173-180)

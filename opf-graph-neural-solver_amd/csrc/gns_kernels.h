@@ -31,6 +31,7 @@ struct GnsFwdArgs {
   const float* in;        // packed inputs
   float* state;           // [slots][G][N][RB][64] float4
   float* lam;             // [K][G][64] float2 (lambda, branch bits) when save != 0
+  float* msg;             // [K][G][N][NPHI][HQ][64] float4: hidden-vector sums, when save != 0
   float* v_out; float* theta_out; float* total_out; float* last_out;
   long long t_off[6], t_sz[6];
   float gw[GNS_MAX_K];    // gamma^(K-k) rounded to fp32 from a double, like the reference's python float
@@ -44,6 +45,7 @@ struct GnsBwdArgs {
   const float* in;                       // packed inputs
   const float* state;                    // saved states S_0..S_K of the forward
   const float* lam;                      // (lambda, branch bits) per step
+  const float* msg;                      // hidden-vector sums per (step, bus, phi family) saved by the forward
   const float* g_total; const float* g_last; const float* g_v; const float* g_theta;   // upstream gradients (nullable)
   float* adj;                            // [G][N][RB][64] float4: (vbar, thbar, dpbar, -) + mbar
   float* slots;                          // [G][6][E][64] per-line physics adjoints
