@@ -11,6 +11,8 @@ library or without a ROCm device the forward raises.
 from .gns import GNS, LearningBlock, get_BLG, GNSError
 from . import synth
 from . import dist
+from . import prepare, metrics, training
+from .prepare import prepare_grids
 from ._lib import load_library, library_path
 
-__all__ = ['GNS', 'LearningBlock', 'get_BLG', 'GNSError', 'synth', 'dist', 'load_library', 'library_path']
+__all__ = ['GNS', 'LearningBlock', 'get_BLG', 'GNSError', 'synth', 'dist', 'prepare', 'metrics', 'training', 'prepare_grids', 'load_library', 'library_path']

@@ -140,3 +140,41 @@ def synth_grids(case_nr: int, batch: int, seed: int = 0, device='cpu', load_scal
     gens[:, :, 5] = qg / BASE_MVA
     gens[:, :, 6] = pg / BASE_MVA
     return buses, lines, gens
+
+
+def raw_case_arrays(case_nr: int, batch: int, seed: int = 0, zero_tau_fraction: float = 0.3):
+    """Synthetic PYPOWER case-format arrays ``bus[B,N,13]``, ``branch[B,E,13]``, ``gen[B,Gn,21]`` (float64, MW / degrees)
+    for the input producer ``prepare.prepare_grids``.  A fraction of the lines carries ratio 0 (= "no transformer" in
+    MATPOWER), which ``GNS/utils.py:33`` maps to 1."""
+    c = base_case(case_nr)
+    n, e, gn = CASE_SHAPES[case_nr]
+    g = torch.Generator().manual_seed(int(seed))
+    f64 = torch.float64
+    u = lambda lo, hi, *s: torch.rand(s, generator=g, dtype=f64) * (hi - lo) + lo
+    T = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64))
+    bus = torch.zeros(batch, n, 13, dtype=f64)
+    bus[:, :, 0] = torch.arange(1, n + 1, dtype=f64)
+    bus[:, :, 1] = 1
+    bus[:, :, 2] = T(c['Pd']) * u(0.5, 1.5, batch, n)
+    bus[:, :, 3] = T(c['Qd']) * u(0.5, 1.5, batch, n)
+    bus[:, :, 4] = u(0.0, 5.0, batch, n)             # Gs, Bs of the raw case are overwritten by prepare_grid
+    bus[:, :, 5] = u(0.0, 20.0, batch, n)
+    bus[:, :, 7], bus[:, :, 9], bus[:, :, 11], bus[:, :, 12] = 1.0, 135.0, 1.06, 0.94
+    br = torch.zeros(batch, e, 13, dtype=f64)
+    br[:, :, 0], br[:, :, 1] = T(c['f_bus']), T(c['t_bus'])
+    br[:, :, 2] = T(c['r']) * u(0.9, 1.1, batch, e)
+    br[:, :, 3] = T(c['x']) * u(0.9, 1.1, batch, e)
+    br[:, :, 4] = T(c['b']) * u(0.9, 1.1, batch, e)
+    tau = u(0.8, 1.2, batch, e)
+    br[:, :, 8] = torch.where(torch.rand(batch, e, generator=g) < zero_tau_fraction, torch.zeros_like(tau), tau)
+    br[:, :, 9] = u(-0.2, 0.2, batch, e)
+    br[:, :, 10], br[:, :, 11], br[:, :, 12] = 1, -360, 360
+    ge = torch.zeros(batch, gn, 21, dtype=f64)
+    ge[:, :, 0] = T(c['gen_bus'])
+    ge[:, :, 8], ge[:, :, 9] = T(c['Pmax']), T(c['Pmin'])
+    ge[:, :, 1] = T(c['Pmin']) + (T(c['Pmax']) - T(c['Pmin'])) * u(0.25, 0.75, batch, gn)
+    ge[:, :, 2] = T(c['Qg'])
+    ge[:, :, 3], ge[:, :, 4] = 100.0, -50.0
+    ge[:, :, 5] = T(c['Vg']) * u(0.95, 1.05, batch, gn)
+    ge[:, :, 6], ge[:, :, 7] = BASE_MVA, 1
+    return bus, br, ge

@@ -1,0 +1,72 @@
+"""Batched training loop around the fused forward/backward: what ``main()`` does at ``GNS/main.py:235-309`` without the
+per-grid Python loop and without wandb.  Data-parallel when ``torch.distributed`` is initialised (one flat-gradient
+all-reduce per step, ``dist.allreduce_gradients``)."""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as tdist
+
+from . import dist as gdist
+from .gns import get_BLG
+
+
+def checkpoint_name(case_nr, K, latent_dim, hidden_dim, multiple_phi, optimizer_name):
+    """File name of the reference's checkpoints (``main.py:308-309``) so that files interchange."""
+    return f'best_model_c{case_nr}_K{K}_L{latent_dim}_H{hidden_dim}_{multiple_phi}_optim{optimizer_name}.pth'
+
+
+def make_optimizer(model, optimizer_name='Adam', lr=None):
+    """``main.py:236-243``: Adagrad with lr 0.01, otherwise Adam with lr 0.001."""
+    if optimizer_name == 'Adagrad':
+        return torch.optim.Adagrad(model.parameters(), lr=0.01 if lr is None else lr)
+    return torch.optim.Adam(model.parameters(), lr=0.001 if lr is None else lr)
+
+
+def train_step(model, optimizer, buses, lines, generators, global_batch=None):
+    """One optimiser step on one batch: mean of the per-grid losses (``main.py:284``), backward, step, zero_grad
+    (``:288-291``).  Returns ``(mean total_loss, mean last_loss)`` as 0-dim tensors (no host sync)."""
+    B, L, G = get_BLG()
+    v, theta, losses, last_losses = model(buses, lines, generators, B, L, G)
+    total = losses.mean()
+    total.backward()
+    if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
+        gdist.allreduce_gradients(model, global_batch=global_batch or buses.shape[0] * tdist.get_world_size(), local_batch=buses.shape[0])
+    optimizer.step()
+    optimizer.zero_grad()
+    return total.detach(), last_losses.detach().mean()
+
+
+def fit(model, all_buses, all_lines, all_generators, *, epochs=101, batch_size=128, optimizer_name='Adam', lr=None, case_nr=14,
+        print_every=1, checkpoint_dir=None, log=print):
+    """Epoch loop of ``main.py:274-309``: batches in order, early stop once the epoch's mean final loss has failed to
+    improve more than twice in a row (``:296-304``), checkpoint every ``print_every`` epochs (``:306-309``).
+
+    Like the reference (where ``best_model = model`` is an alias, ``main.py:303``) the checkpoint holds the CURRENT
+    parameters.  Returns the list of epoch mean final losses."""
+    optimizer = make_optimizer(model, optimizer_name, lr)
+    nr_samples = all_buses.shape[0]
+    best, bad, history = float('inf'), 0, []
+    for epoch in range(epochs):
+        finals = []
+        for lo in range(0, nr_samples - batch_size + 1, batch_size):
+            sl = slice(lo, lo + batch_size)
+            _, last = train_step(model, optimizer, all_buses[sl], all_lines[sl], all_generators[sl])
+            finals.append(last)
+        epoch_final = float(torch.stack(finals).mean()) if finals else float('nan')
+        history.append(epoch_final)
+        if epoch_final >= best:
+            bad += 1
+            if bad > 2:
+                log('Loss is increasing')
+                break
+        else:
+            best, bad = epoch_final, 0
+        if epoch % print_every == 0:
+            log(f'Epoch: {epoch}, Final Loss: {epoch_final}, best loss: {best}')
+            if checkpoint_dir is not None:
+                os.makedirs(checkpoint_dir, exist_ok=True)
+                torch.save(model.state_dict(), os.path.join(checkpoint_dir, checkpoint_name(
+                    case_nr, model.K, model.latent_dim, model.hidden_dim, model.multiple_phis, optimizer_name)))
+    return history

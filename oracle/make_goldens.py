@@ -114,9 +114,36 @@ def run_case(ref, synth, name, case_nr, batch, K, d, h, multi, seed, load_scale=
           f'none_grad={len(none_grad)}')
 
 
+def run_prepare(synth, name, case_nr, batch, seed):
+    """Golden for the input producer: the reference's OWN utils.prepare_grid (GNS/utils.py:17-41) executed on synthetic
+    PYPOWER-format case dicts.  Its file access is the only thing replaced: ``open`` / ``pkl.load`` inside the module
+    are pointed at the in-memory dict (the shipped pickles are not readable with a non-executing loader)."""
+    import utils as ref_utils
+    bus, br, ge = synth.raw_case_arrays(case_nr, batch, seed=seed)
+    outs = []
+    holder = {}
+    ref_utils.open = lambda *a, **k: None
+    orig = ref_utils.pkl.load
+    ref_utils.pkl.load = lambda f: holder['case']
+    try:
+        for b in range(batch):
+            holder['case'] = {'baseMVA': 100.0, 'bus': bus[b].numpy(), 'branch': br[b].numpy(), 'gen': ge[b].numpy()}
+            outs.append([t.numpy() for t in ref_utils.prepare_grid(case_nr, b)])
+    finally:
+        ref_utils.pkl.load = orig
+        del ref_utils.open
+    path = os.path.join(ROOT, 'tests', 'golden', name + '.npz')
+    np.savez_compressed(path, kind='prepare', case_nr=case_nr, bus=bus.numpy(), branch=br.numpy(), gen=ge.numpy(),
+                        buses=np.stack([o[0] for o in outs]), lines=np.stack([o[1] for o in outs]),
+                        generators=np.stack([o[2] for o in outs]))
+    print(f'{name}: wrote {os.path.getsize(path) / 1024:.0f} KiB')
+
+
 def main():
     ref = _import_reference()
     synth = _load_pkg()
+    run_prepare(synth, 'prepare_c14_b4', 14, 4, 21)
+    run_prepare(synth, 'prepare_c118_b2', 118, 2, 22)
     os.makedirs(os.path.join(ROOT, 'tests', 'golden'), exist_ok=True)
     # name, case, batch, K, d, h, multi, seed, load_scale
     cases = [

@@ -10,7 +10,9 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 
 def golden_names():
-    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, '*.npz')))
+    """forward/backward goldens (the prepare_* files are goldens of the input producer)"""
+    names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, '*.npz')))
+    return [n for n in names if not n.startswith('prepare_')]
 
 
 def load_golden(name):
