@@ -160,3 +160,22 @@ def test_error_behaviour_on_device():
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
+
+
+def test_more_groups_than_backward_workgroups():
+    """20 000 case14 grids = 313 wave-groups > the 256 persistent backward workgroups: slabs accumulate across groups."""
+    import opf_graph_neural_solver_amd as amd
+    torch.manual_seed(3)
+    m = amd.GNS(10, 10, 2, 0.9, True).cuda()
+    bt = 20000
+    bu, li, ge = amd.synth.synth_grids(14, bt, seed=9, device='cuda')
+    _, _, tot, _ = m(bu, li, ge)
+    tot.mean().backward()
+    g_all = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
+    parts = []
+    for lo, hi in ((0, 8000), (8000, 20000)):
+        m.zero_grad()
+        _, _, t_h, _ = m(bu[lo:hi], li[lo:hi], ge[lo:hi])
+        t_h.sum().backward()
+        parts.append(torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone())
+    assert_close(((parts[0] + parts[1]) / bt).cpu(), g_all.cpu(), 2e-5, abs_floor=1e-7, what='20000-grid gradient')
