@@ -44,6 +44,8 @@ enum {
   TH_INCD_PTR,  // [N+1] incidence list of the delta adjoints (backward)
   TH_INCD,      // [4E]  p*4 + code ; code 0:+dbar 1:-dbar 2:+dbar' 3:-dbar'
   TH_IN_DST,    // [E]   t = dst[e] of in-edge p
+  TH_UPART,     // [GNS_NPART][GNS_MAXW+1] forward update phase: ranges of (family, bus) units u = f*N + n, balanced by work
+  TH_PPART,     // [GNS_NPART][GNS_MAXW+1] forward physics phase: bus ranges balanced by incident lines
   TH_TOTAL,     // blob length in words
   TH_HDR_WORDS = 32
 };
@@ -122,7 +124,7 @@ struct GnsFwdLayout {
   int64_t groups;        // ceil(Bt/64)
   int64_t mq;            // float4 rows holding the latent vector: ceil(d/4)
   int64_t rows_bus;      // 1 + mq
-  int64_t slots;         // K+1 when the state is saved for backward, else 1
+  int64_t slots;         // K+1 when the state is saved for backward, else 2
   size_t off_pt, off_pn, off_in, off_lam, off_state, off_msg, total;
 };
 
@@ -133,7 +135,7 @@ static inline void gns_fwd_layout(int N, int E, int d, int h, int K, int multi, 
   L->groups = (Bt + GNS_LANES - 1) / GNS_LANES;
   L->mq = (d + 3) / 4;
   L->rows_bus = 1 + L->mq;
-  L->slots = save ? K + 1 : 1;
+  L->slots = save ? K + 1 : 2;    // inference ping-pongs between two slots (families of one bus are updated by different waves)
   size_t o = 0;
   L->off_pt = o;    o = gns_align256(o + (size_t)f.t_total * 4);
   L->off_pn = o;    o = gns_align256(o + (size_t)f.n_total * 4);

@@ -151,6 +151,9 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
             out_c = topo + topo[TH_OUT_C], out_d = topo + topo[TH_OUT_D], is_gen = topo + topo[TH_IS_GEN],
             part = topo + topo[TH_PART] + A.part_idx * (GNS_MAXW + 1);
   const int n0 = part[wave], n1 = part[wave + 1];
+  const cip upart = topo + topo[TH_UPART] + A.part_idx * (GNS_MAXW + 1), ppart = topo + topo[TH_PPART] + A.part_idx * (GNS_MAXW + 1);
+  const int u0 = upart[wave], u1 = upart[wave + 1];       // (family, bus) units of the update phase, family-major
+  const int q0w = ppart[wave], q1w = ppart[wave + 1];     // buses of the physics phase
   const long long R = gns_in_rows(N, E);
   const float* IN = A.in;
   const long long in_base = g * R;
@@ -170,75 +173,83 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
 #pragma unroll
     for (int q = 0; q < MQ; ++q) *row_ptr(A.state, r0 + 1 + q, lane) = f4{0.f, 0.f, 0.f, 0.f};
   }
+  __syncthreads();                                  // the update phase reads buses initialised by other waves
   const f4 gsum = *row_ptr(IN, row_grid, lane);     // (sumPd, sumPset, sumPmin, sumPmax)
   float tot_part = 0.f, last_part = 0.f;
   const float invN = 1.0f / (float)N;
 
+#ifdef GNS_STAMPS
+  long long tph[6] = {0, 0, 0, 0, 0, 0};
+  long long tlast = clock64();
+#define FSTAMP(i) { const long long tn = clock64(); tph[i] += tn - tlast; tlast = tn; }
+#else
+#define FSTAMP(i)
+#endif
   for (int k = 0; k < K; ++k) {
-    const int rs = A.save ? k : 0, ws = A.save ? k + 1 : 0;
+    const int rs = A.save ? k : (k & 1), ws = A.save ? k + 1 : ((k + 1) & 1);
+    FSTAMP(5)
     const long long koff = (long long)k;
-    // ================= phase U: latent / v / theta update, one bus at a time (main.py:155-188) ========
-    for (int n = n0; n < n1; ++n) {
+    // ================= phase U: latent / v / theta update (main.py:155-188) =================================
+    // Work unit = (family, bus): family theta writes theta, family v writes v, family m writes the latent vector.
+    // Units are dealt family-major so that a wave streams one family's weights (scalar-cache resident) and the 16
+    // waves balance to a few per cent (whole buses of 750..5500 instructions left 16 % of the time at the barrier).
+    auto update_unit = [&](auto l_, int n) {
+      constexpr int l = decltype(l_)::value;                // 0 = L_theta, 1 = L_v, 2 = L_m   (main.py:173-180)
+      constexpr int fphi = MULTI ? (l == 0 ? 1 : (l == 1 ? 0 : 2)) : 0;   // phi_theta, phi_v, phi_m
       const long long rr = state_row(rs, n), wr = state_row(ws, n);
       const f4 s0 = *row_ptr(A.state, rr, lane);
       f2 m[D / 2];
       load_pairs<D>(A.state, rr + 1, lane, m);
       const int p0 = in_ptr[n], p1 = in_ptr[n + 1];
-      float upd_theta, upd_v;
-      f2 upd_m[D / 2];
-      f2 S[H / 2];                  // sum over the lines ending at n of the hidden vector of phi' (one family at a time)
-      const float degf = (float)(p1 - p0);
-      auto message_sum = [&](auto f_) {                // main.py:155-163 with the output layer of phi folded into L'
-        constexpr int f = decltype(f_)::value;
+      f2 x[(C::LF_IN + 1) / 2];                             // [v theta | dp dq | m | sum h | deg]
+      f2 (&S)[H / 2] = reinterpret_cast<f2 (&)[H / 2]>(x[2 + D / 2]);
 #pragma unroll
-        for (int j = 0; j < H / 2; ++j) S[j] = f2{0.f, 0.f};
-        for (int p = p0; p < p1; ++p) {
-          const f4 e0 = *row_ptr(IN, row_ein + 3LL * p, lane), e1 = *row_ptr(IN, row_ein + 3LL * p + 1, lane);
-          f2 x[(C::PHI_IN + 1) / 2];
+      for (int j = 0; j < H / 2; ++j) S[j] = f2{0.f, 0.f};
+      for (int p = p0; p < p1; ++p) {                       // main.py:155-163 with the output layer of phi folded into L'
+        const f4 e0 = *row_ptr(IN, row_ein + 3LL * p, lane), e1 = *row_ptr(IN, row_ein + 3LL * p + 1, lane);
+        f2 xe[(C::PHI_IN + 1) / 2];
 #pragma unroll
-          for (int i = 0; i < D / 2; ++i) x[i] = m[i];
-          x[D / 2] = f2{e0.x, e0.y}; x[D / 2 + 1] = f2{e0.z, e0.w}; x[D / 2 + 2] = f2{e1.x, 0.f};
-          f2 a1[H / 2], a2[H / 2];
-          mlp2_fwd<C::PHI_IN, H>(PT + A.t_off[f] + koff * A.t_sz[f], x, a1, a2);
-#pragma unroll
-          for (int j = 0; j < H / 2; ++j) S[j] += a2[j];
-        }
-        if (A.save) store_pairs<H>(A.msg, ((((long long)k * A.G + g) * N + n) * C::NPHI + f) * C::HQ, lane, S);
-      };
-      if constexpr (!MULTI) message_sum(std::integral_constant<int, 0>{});
-      static_for<0, 3>([&](auto l_) {                  // l: 0 = L_theta, 1 = L_v, 2 = L_m   (main.py:173-180)
-        constexpr int l = decltype(l_)::value;
-        constexpr int fphi = MULTI ? (l == 0 ? 1 : (l == 1 ? 0 : 2)) : 0;   // phi_theta, phi_v, phi_m
-        if constexpr (MULTI) message_sum(std::integral_constant<int, fphi>{});
-        f2 x[(C::LF_IN + 1) / 2];                      // [v theta | dp dq | m | sum h | deg]
-        x[0] = f2{s0.x, s0.y}; x[1] = f2{s0.z, s0.w};
-#pragma unroll
-        for (int i = 0; i < D / 2; ++i) x[2 + i] = m[i];
-#pragma unroll
-        for (int i = 0; i < H / 2; ++i) x[2 + D / 2 + i] = S[i];
-        x[2 + D / 2 + H / 2] = f2{degf, 0.f};
+        for (int i = 0; i < D / 2; ++i) xe[i] = m[i];
+        xe[D / 2] = f2{e0.x, e0.y}; xe[D / 2 + 1] = f2{e0.z, e0.w}; xe[D / 2 + 2] = f2{e1.x, 0.f};
         f2 a1[H / 2], a2[H / 2];
-        if constexpr (l < 2) {
-          f2 y[1];
-          mlp_fwd<C::LF_IN, H, 2>(PT + A.t_off[C::NPHI + l] + koff * A.t_sz[C::NPHI + l], x, a1, a2, y);
-          if constexpr (l == 0) upd_theta = y[0].x; else upd_v = y[0].x;
-        } else {
-          mlp_fwd<C::LF_IN, H, D>(PT + A.t_off[C::NPHI + 2] + koff * A.t_sz[C::NPHI + 2], x, a1, a2, upd_m);
-        }
-      });
-      const float th_new = s0.y + upd_theta;                          // main.py:182
-      const float v_new = is_gen[n] ? s0.x : s0.x + upd_v;           // main.py:184-186
-      *row_ptr(A.state, wr, lane) = f4{v_new, th_new, 0.f, 0.f};
-      f2 m_new[D / 2];
+        mlp2_fwd<C::PHI_IN, H>(PT + A.t_off[fphi] + koff * A.t_sz[fphi], xe, a1, a2);
 #pragma unroll
-      for (int i = 0; i < D / 2; ++i) m_new[i] = m[i] + upd_m[i];     // main.py:188
-      store_pairs<D>(A.state, wr + 1, lane, m_new);
+        for (int j = 0; j < H / 2; ++j) S[j] += a2[j];
+      }
+      if (A.save && (MULTI || l == 0))
+        store_pairs<H>(A.msg, ((((long long)k * A.G + g) * N + n) * C::NPHI + fphi) * C::HQ, lane, S);
+      x[0] = f2{s0.x, s0.y}; x[1] = f2{s0.z, s0.w};
+#pragma unroll
+      for (int i = 0; i < D / 2; ++i) x[2 + i] = m[i];
+      x[2 + D / 2 + H / 2] = f2{(float)(p1 - p0), 0.f};
+      f2 a1[H / 2], a2[H / 2];
+      if constexpr (l < 2) {
+        f2 y[1];
+        mlp_fwd<C::LF_IN, H, 2>(PT + A.t_off[C::NPHI + l] + koff * A.t_sz[C::NPHI + l], x, a1, a2, y);
+        float* r0 = reinterpret_cast<float*>(row_ptr(A.state, wr, lane));
+        if constexpr (l == 0) r0[1] = s0.y + y[0].x;                       // theta += L_theta        (main.py:182)
+        else r0[0] = is_gen[n] ? s0.x : s0.x + y[0].x;                     // v += L_v off generators (main.py:184-186)
+      } else {
+        f2 upd_m[D / 2], m_new[D / 2];
+        mlp_fwd<C::LF_IN, H, D>(PT + A.t_off[C::NPHI + 2] + koff * A.t_sz[C::NPHI + 2], x, a1, a2, upd_m);
+#pragma unroll
+        for (int i = 0; i < D / 2; ++i) m_new[i] = m[i] + upd_m[i];        // main.py:188
+        store_pairs<D>(A.state, wr + 1, lane, m_new);
+      }
+    };
+    for (int u = u0; u < u1; ++u) {
+      const int f = u / N, n = u - f * N;
+      if (f == 0) update_unit(std::integral_constant<int, 0>{}, n);
+      else if (f == 1) update_unit(std::integral_constant<int, 1>{}, n);
+      else update_unit(std::integral_constant<int, 2>{}, n);
     }
+    FSTAMP(0)
     __syncthreads();   // every bus of the 64 grids now has v_{k+1}, theta_{k+1}
+    FSTAMP(1)
 
     // ================= phase P: line physics (main.py:34-104), bus-centric, no scatter ================
     float joule = 0.f, v2gs = 0.f;
-    for (int n = n0; n < n1; ++n) {
+    for (int n = q0w; n < q1w; ++n) {
       const long long wr = state_row(ws, n);
       const f4 sn = *row_ptr(A.state, wr, lane);
       const float vn = sn.x, thn = sn.y;
@@ -289,9 +300,11 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
       const float dq = ((qg_new - b0.y) + b0.w * v2) + sum_qf + sum_qt;      // main.py:83,103 (cancels to rounding noise)
       *row_ptr(A.state, wr, lane) = f4{vn, thn, dp_pre, dq};
     }
+    FSTAMP(2)
     red[k & 1][wave][lane][0] = joule;
     red[k & 1][wave][lane][1] = v2gs;
     __syncthreads();
+    FSTAMP(3)
     float jsum = 0.f, vsum = 0.f;
     for (int w = 0; w < nwaves; ++w) { jsum += red[k & 1][w][lane][0]; vsum += red[k & 1][w][lane][1]; }
     // global active compensation (main.py:45-57)
@@ -304,7 +317,7 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
     if (A.save && wave == 0)
       reinterpret_cast<f2*>(A.lam)[((long long)k * A.G + g) * GNS_LANES + lane] = f2{lam, (low1 ? 1.f : 0.f) + (low2 ? 2.f : 0.f)};
     float sq = 0.f;
-    for (int n = n0; n < n1; ++n) {
+    for (int n = q0w; n < q1w; ++n) {
       const long long wr = state_row(ws, n);
       const f4 b1 = *row_ptr(IN, in_base + 3LL * n + 1, lane);         // Pmin,Pset,Pmax,v0 summed per bus
       f4 sn = *row_ptr(A.state, wr, lane);
@@ -315,10 +328,15 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
     }
     tot_part += A.gw[k] * (sq * invN);           // main.py:198
     last_part = sq * invN;                                            // main.py:199
+    __syncthreads();                                                  // dp_{k+1} is complete before any wave starts step k+1
+    FSTAMP(4)
   }
+#ifdef GNS_STAMPS
+  if (lane == 0) for (int i = 0; i < 6; ++i) A.lam[((long long)blockIdx.x * nwaves + wave) * 6 + i] = (float)tph[i];   // diagnostic build: the lambda buffer is dead by now (eval mode)
+#endif
 
   // ---- epilogue: outputs (main.py:199-202) ---------------------------------------------------------
-  const int fs = A.save ? K : 0;
+  const int fs = A.save ? K : (K & 1);
   if (live) {
     for (int n = n0; n < n1; ++n) {
       const f4 sn = *row_ptr(A.state, state_row(fs, n), lane);

@@ -93,10 +93,21 @@ int build(int N, int E, int Gn, const int32_t* src, const int32_t* dst, const in
     cost[n] = 950.0 + 1075.0 * din + 150.0 * dout + 10.0 * (incd_ptr[n + 1] - incd_ptr[n]);
   }
   std::vector<int32_t> part(GNS_NPART * (GNS_MAXW + 1)), epart(GNS_NPART * (GNS_MAXW + 1));
+  std::vector<int32_t> upart(GNS_NPART * (GNS_MAXW + 1)), ppart(GNS_NPART * (GNS_MAXW + 1));
+  // forward: (family, bus) units in family-major order (one family's weights stay hot in the scalar cache);
+  // packed-FMA instruction estimates of the folded networks: L' ~ 300 (theta, v) / 400 (m), phi' ~ 190 per line
+  std::vector<double> ucost(3 * (size_t)N), pcost(N);
+  for (int f = 0; f < 3; ++f)
+    for (int n = 0; n < N; ++n) ucost[(size_t)f * N + n] = (f == 2 ? 400.0 : 300.0) + 190.0 * (in_ptr[n + 1] - in_ptr[n]);
+  // (waves of a workgroup do not run at equal speed: VALU issue favours the older waves of a SIMD, so the youngest four
+  //  finish last whatever they are given; weighting their share down was measured slower, the SIMD total is what counts)
+  for (int n = 0; n < N; ++n) pcost[n] = 60.0 + 130.0 * (in_ptr[n + 1] - in_ptr[n]) + 80.0 * (out_ptr[n + 1] - out_ptr[n]);
   const int wopts[GNS_NPART] = {1, 2, 4, 8, 16};
   for (int i = 0; i < GNS_NPART; ++i) {
     balanced_ranges(cost, wopts[i], &part[i * (GNS_MAXW + 1)]);
     balanced_ranges(ecost, wopts[i], &epart[i * (GNS_MAXW + 1)]);
+    balanced_ranges(ucost, wopts[i], &upart[i * (GNS_MAXW + 1)]);
+    balanced_ranges(pcost, wopts[i], &ppart[i * (GNS_MAXW + 1)]);
   }
 
   b.put(TH_IN_PTR, in_ptr); b.put(TH_IN_EID, in_eid); b.put(TH_IN_SRC, in_src); b.put(TH_IN_A, in_a); b.put(TH_IN_B, in_b);
@@ -104,6 +115,7 @@ int build(int N, int E, int Gn, const int32_t* src, const int32_t* dst, const in
   b.put(TH_IS_GEN, is_gen); b.put(TH_GEN_PTR, gen_ptr); b.put(TH_GEN_IDX, gen_idx);
   b.put(TH_PART, part); b.put(TH_P2Q, p2q); b.put(TH_Q2P, q2p); b.put(TH_EPART, epart);
   b.put(TH_INCD_PTR, incd_ptr); b.put(TH_INCD, incd); b.put(TH_IN_DST, in_dst);
+  b.put(TH_UPART, upart); b.put(TH_PPART, ppart);
   b.w[TH_TOTAL] = (int32_t)b.w.size();
   out.swap(b.w);
   return GNS_OK;
@@ -111,7 +123,7 @@ int build(int N, int E, int Gn, const int32_t* src, const int32_t* dst, const in
 
 size_t blob_words(int N, int E, int Gn) {
   return TH_HDR_WORDS + 2 * (size_t)(N + 1) + 12 * (size_t)E + (size_t)N + (size_t)(N + 1) + (size_t)std::max(Gn, 1)
-         + 2 * (size_t)GNS_NPART * (GNS_MAXW + 1) + (size_t)(N + 1) + 5 * (size_t)E;
+         + 4 * (size_t)GNS_NPART * (GNS_MAXW + 1) + (size_t)(N + 1) + 5 * (size_t)E;
 }
 
 }  // namespace

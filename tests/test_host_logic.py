@@ -86,7 +86,7 @@ def test_topology_blob(case):
     assert lib.gns_prepare_topology(N, E, Gn, src.ctypes.data, dst.ctypes.data, gen.ctypes.data, blob.ctypes.data, blob.nbytes) == 0
     H = {k: i for i, k in enumerate(['MAGIC', 'N', 'E', 'GN', 'IN_PTR', 'IN_EID', 'IN_SRC', 'IN_A', 'IN_B', 'OUT_PTR', 'OUT_EID',
                                      'OUT_DST', 'OUT_C', 'OUT_D', 'IS_GEN', 'GEN_PTR', 'GEN_IDX', 'PART', 'P2Q', 'Q2P', 'EPART',
-                                     'INCD_PTR', 'INCD', 'IN_DST', 'TOTAL'])}
+                                     'INCD_PTR', 'INCD', 'IN_DST', 'UPART', 'PPART', 'TOTAL'])}
     arr = lambda k, n: blob[blob[H[k]]:blob[H[k]] + n]
     assert blob[H['N']] == N and blob[H['E']] == E and blob[H['GN']] == Gn and blob[H['TOTAL']] <= blob.size
     in_order, out_order = _py_topology(src, dst, N)
@@ -108,6 +108,11 @@ def test_topology_blob(case):
         assert part[0] == 0 and part[W] == N and np.all(np.diff(part) >= 0)
     incd_ptr = arr('INCD_PTR', N + 1)
     assert incd_ptr[N] == 4 * E
+    for wi, W in enumerate((1, 2, 4, 8, 16)):
+        up = blob[blob[H['UPART']] + wi * 17: blob[H['UPART']] + wi * 17 + 17]
+        pp = blob[blob[H['PPART']] + wi * 17: blob[H['PPART']] + wi * 17 + 17]
+        assert up[0] == 0 and up[W] == 3 * N and np.all(np.diff(up) >= 0)        # (family, bus) units of the forward update phase
+        assert pp[0] == 0 and pp[W] == N and np.all(np.diff(pp) >= 0)
 
 
 def test_topology_rejects_bad_ids():
