@@ -26,17 +26,18 @@ def flat_gradient(model) -> torch.Tensor:
     grads = [p.grad for p in params]
     if any(g is None for g in grads):
         raise RuntimeError('flat_gradient: a parameter has no gradient (run backward first)')
-    base = grads[0]._base if grads[0]._base is not None else grads[0]
-    off, ok = 0, base.dim() == 1 and base.is_contiguous()
+    # autograd keeps the views it was handed but detaches them (``_base`` is lost), so contiguity is checked on the storage
+    g0 = grads[0]
+    st, off, ok = g0.untyped_storage(), g0.storage_offset(), True
+    for g in grads:
+        if (g.dtype != g0.dtype or g.device != g0.device or not g.is_contiguous() or g.storage_offset() != off
+                or g.untyped_storage().data_ptr() != st.data_ptr()):
+            ok = False
+            break
+        off += g.numel()
     if ok:
-        for g in grads:
-            if (g._base is not base and g is not base) or g.storage_offset() != base.storage_offset() + off or not g.is_contiguous():
-                ok = False
-                break
-            off += g.numel()
-        ok = ok and off == base.numel()
-    if ok:
-        return base
+        total = off - g0.storage_offset()
+        return torch.empty(0, dtype=g0.dtype, device=g0.device).set_(st, g0.storage_offset(), (total,))
     flat = torch.cat([g.reshape(-1) for g in grads])
     off = 0
     for p in params:
