@@ -53,7 +53,7 @@ def allreduce_gradients(model, global_batch: int | None = None, local_batch: int
     result is rescaled to the gradient of the mean over the global batch (what the reference's single-process
     ``torch.mean(losses).backward()`` yields, GNS/main.py:284-288)."""
     flat = flat_gradient(model)
-    if global_batch is not None and local_batch is not None:
+    if global_batch is not None and local_batch is not None and local_batch != global_batch:
         flat.mul_(float(local_batch) / float(global_batch))
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
