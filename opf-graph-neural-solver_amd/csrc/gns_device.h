@@ -41,21 +41,32 @@ __device__ __forceinline__ void touch(const f16v& v) { asm volatile("" ::"s"(v[0
 
 template <int NF, class F>
 __device__ __forceinline__ void stream_pairs(cfp p, F&& f) {
-  constexpr int NCH = (NF + 15) / 16;
+  // 32-float steps: two s_load_dwordx16 are in flight while the previous 32 floats feed 16 packed FMAs
+  constexpr int NST = (NF + 31) / 32;
   p += opaque_zero();
-  f16v bufA, bufB;
-  bufA = *(cf16p)(p);
-  static_for<0, NCH>([&](auto c_) {
+  f16v a0, a1, b0, b1;
+  a0 = *(cf16p)(p);
+  a1 = *(cf16p)(p + 16);
+  static_for<0, NST>([&](auto c_) {
     constexpr int c = decltype(c_)::value;
-    f16v& cur = (c & 1) ? bufB : bufA;
-    f16v& nxt = (c & 1) ? bufA : bufB;
-    touch(cur);
-    if constexpr (c + 1 < NCH) nxt = *(cf16p)(p + 16 * (c + 1));
+    f16v& c0 = (c & 1) ? b0 : a0;
+    f16v& c1 = (c & 1) ? b1 : a1;
+    f16v& n0 = (c & 1) ? a0 : b0;
+    f16v& n1 = (c & 1) ? a1 : b1;
+    touch(c0);
+    touch(c1);
+    if constexpr (c + 1 < NST) {
+      n0 = *(cf16p)(p + 32 * (c + 1));
+      n1 = *(cf16p)(p + 32 * (c + 1) + 16);
+    }
     __builtin_amdgcn_sched_barrier(0);
-    static_for<0, 8>([&](auto t_) {
+    static_for<0, 16>([&](auto t_) {
       constexpr int t = decltype(t_)::value;
-      constexpr int w = c * 16 + 2 * t;
-      if constexpr (w < NF) f(std::integral_constant<int, w>{}, f2{cur[2 * t], cur[2 * t + 1]});
+      constexpr int w = c * 32 + 2 * t;
+      if constexpr (w < NF) {
+        if constexpr (t < 8) f(std::integral_constant<int, w>{}, f2{c0[2 * t], c0[2 * t + 1]});
+        else f(std::integral_constant<int, w>{}, f2{c1[2 * (t - 8)], c1[2 * (t - 8) + 1]});
+      }
     });
     __builtin_amdgcn_sched_barrier(0);
   });
