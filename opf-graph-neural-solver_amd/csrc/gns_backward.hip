@@ -330,13 +330,20 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
       const int bits = (int)lamv.y;
       const bool low1 = bits & 1, low2 = bits & 2;
 
-      // ---------------- Pb-0 ----------------
+      // ---------------- Pb-0 (also closes step k+1: identity paths + the input adjoints its sweeps collected) --------
       float lb = 0.f;
       for (int n = n0; n < n1; ++n) {
+        const long long ar = adj_row(n);
         const f4 s1 = *row_ptr(A.state, state_row(k + 1, n), lane);
-        f4 a0 = *row_ptr(A.adj, adj_row(n), lane);
+        f4 a0 = *row_ptr(A.adj, ar, lane);
+        if (k < K - 1) {
+          const f4 xsum = *row_ptr(A.adj, ar + 1, lane);
+          a0 = f4{a0.x + xsum.x, a0.y + xsum.y, xsum.z, 0.f};               // main.py:182,186 identity paths
+#pragma unroll
+          for (int q = 0; q < 1 + RHB; ++q) *row_ptr(A.adj, ar + 1 + q, lane) = f4{0.f, 0.f, 0.f, 0.f};
+        }
         a0.z = a0.z + cdp * s1.z;
-        *row_ptr(A.adj, adj_row(n), lane) = a0;
+        *row_ptr(A.adj, ar, lane) = a0;
         const f4 b1 = *row_ptr(IN, in_base + 3LL * n + 1, lane);            // Pmin,Pset,Pmax per bus
         lb += a0.z * (low2 ? 2.f * (b1.y - b1.x) : 2.f * (b1.z - b1.y));    // d Pg_new / d lambda  (main.py:53-57)
       }
@@ -546,14 +553,6 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
           store_pairs<D>(A.adj, ar + RM, lane, macc);
         }
         dw_flush2<C::PHI_IN, H>(lane, TP, accP, slab + A.g_off[0] + koff * A.g_sz[0]);
-      }
-      // ---------------- finalize: (vbar, thbar)_k = identity path + input adjoints; dpbar_k for the next Pb-0 -----------
-      for (int n = n0; n < n1; ++n) {
-        const long long ar = adj_row(n);
-        const f4 a0 = *row_ptr(A.adj, ar, lane), xsum = *row_ptr(A.adj, ar + 1, lane);
-        *row_ptr(A.adj, ar, lane) = f4{a0.x + xsum.x, a0.y + xsum.y, xsum.z, 0.f};     // main.py:182,186 identity paths
-#pragma unroll
-        for (int q = 0; q < 1 + RHB; ++q) *row_ptr(A.adj, ar + 1 + q, lane) = f4{0.f, 0.f, 0.f, 0.f};
       }
       STAMP(8)
     }
