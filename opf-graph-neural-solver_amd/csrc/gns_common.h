@@ -44,7 +44,7 @@ enum {
   TH_INCD_PTR,  // [N+1] incidence list of the delta adjoints (backward)
   TH_INCD,      // [4E]  p*4 + code ; code 0:+dbar 1:-dbar 2:+dbar' 3:-dbar'
   TH_IN_DST,    // [E]   t = dst[e] of in-edge p
-  TH_UPART,     // [GNS_NPART][GNS_MAXW+1] forward update phase: ranges of (family, bus) units u = f*N + n, balanced by work
+  TH_UPART,     // [GNS_NPART][GNS_MAXW+1] forward update phase: ranges of units u = grp*N + n (grp 0: theta+v, 1: m), balanced by work
   TH_PPART,     // [GNS_NPART][GNS_MAXW+1] forward physics phase: bus ranges balanced by incident lines
   TH_TOTAL,     // blob length in words
   TH_HDR_WORDS = 32

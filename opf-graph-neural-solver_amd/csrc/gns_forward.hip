@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
             part = topo + topo[TH_PART] + A.part_idx * (GNS_MAXW + 1);
   const int n0 = part[wave], n1 = part[wave + 1];
   const cip upart = topo + topo[TH_UPART] + A.part_idx * (GNS_MAXW + 1), ppart = topo + topo[TH_PPART] + A.part_idx * (GNS_MAXW + 1);
-  const int u0 = upart[wave], u1 = upart[wave + 1];       // (family, bus) units of the update phase, family-major
+  const int u0 = upart[wave], u1 = upart[wave + 1];       // (family group, bus) units of the update phase, group-major
   const int q0w = ppart[wave], q1w = ppart[wave + 1];     // buses of the physics phase
   const long long R = gns_in_rows(N, E);
   const float* IN = A.in;
@@ -193,55 +193,72 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
     // Work unit = (family, bus): family theta writes theta, family v writes v, family m writes the latent vector.
     // Units are dealt family-major so that a wave streams one family's weights (scalar-cache resident) and the 16
     // waves balance to a few per cent (whole buses of 750..5500 instructions left 16 % of the time at the barrier).
-    auto update_unit = [&](auto l_, int n) {
-      constexpr int l = decltype(l_)::value;                // 0 = L_theta, 1 = L_v, 2 = L_m   (main.py:173-180)
-      constexpr int fphi = MULTI ? (l == 0 ? 1 : (l == 1 ? 0 : 2)) : 0;   // phi_theta, phi_v, phi_m
+    // unit group 0 = the theta and v families of one bus together (one load of the bus state and of the line rows,
+    // 8.9 KB of weights), unit group 1 = the m family.  The forward is HBM-bound in training mode, so re-reading the
+    // state once per family costs more than the second family's weights in the scalar cache.
+    auto update_unit = [&](auto grp_, int n) {
+      constexpr int grp = decltype(grp_)::value;
+      constexpr int NL = grp == 0 ? 2 : 1, L0 = grp == 0 ? 0 : 2;      // L_theta, L_v | L_m   (main.py:173-180)
       const long long rr = state_row(rs, n), wr = state_row(ws, n);
       const f4 s0 = *row_ptr(A.state, rr, lane);
       f2 m[D / 2];
       load_pairs<D>(A.state, rr + 1, lane, m);
       const int p0 = in_ptr[n], p1 = in_ptr[n + 1];
-      f2 x[(C::LF_IN + 1) / 2];                             // [v theta | dp dq | m | sum h | deg]
-      f2 (&S)[H / 2] = reinterpret_cast<f2 (&)[H / 2]>(x[2 + D / 2]);
+      f2 S[NL][H / 2];                                      // sum over the lines ending at n of the hidden vector of phi'
 #pragma unroll
-      for (int j = 0; j < H / 2; ++j) S[j] = f2{0.f, 0.f};
+      for (int j = 0; j < NL; ++j)
+#pragma unroll
+        for (int q = 0; q < H / 2; ++q) S[j][q] = f2{0.f, 0.f};
       for (int p = p0; p < p1; ++p) {                       // main.py:155-163 with the output layer of phi folded into L'
         const f4 e0 = *row_ptr(IN, row_ein + 3LL * p, lane), e1 = *row_ptr(IN, row_ein + 3LL * p + 1, lane);
         f2 xe[(C::PHI_IN + 1) / 2];
 #pragma unroll
         for (int i = 0; i < D / 2; ++i) xe[i] = m[i];
         xe[D / 2] = f2{e0.x, e0.y}; xe[D / 2 + 1] = f2{e0.z, e0.w}; xe[D / 2 + 2] = f2{e1.x, 0.f};
+        static_for<0, (MULTI ? NL : 1)>([&](auto j_) {
+          constexpr int j = decltype(j_)::value;
+          constexpr int l = L0 + j;
+          constexpr int fphi = MULTI ? (l == 0 ? 1 : (l == 1 ? 0 : 2)) : 0;   // phi_theta, phi_v, phi_m
+          f2 a1[H / 2], a2[H / 2];
+          mlp2_fwd<C::PHI_IN, H>(PT + A.t_off[fphi] + koff * A.t_sz[fphi], xe, a1, a2);
+#pragma unroll
+          for (int q = 0; q < H / 2; ++q) S[j][q] += a2[q];
+        });
+      }
+      static_for<0, NL>([&](auto j_) {
+        constexpr int j = decltype(j_)::value;
+        constexpr int l = L0 + j;
+        constexpr int fphi = MULTI ? (l == 0 ? 1 : (l == 1 ? 0 : 2)) : 0;
+        constexpr int js = MULTI ? j : 0;                   // the single phi: one sum serves all three L nets (main.py:169-171)
+        if (A.save && (MULTI || l == 0))
+          store_pairs<H>(A.msg, ((((long long)k * A.G + g) * N + n) * C::NPHI + fphi) * C::HQ, lane, S[js]);
+        f2 x[(C::LF_IN + 1) / 2];                           // [v theta | dp dq | m | sum h | deg]
+        x[0] = f2{s0.x, s0.y}; x[1] = f2{s0.z, s0.w};
+#pragma unroll
+        for (int i = 0; i < D / 2; ++i) x[2 + i] = m[i];
+#pragma unroll
+        for (int q = 0; q < H / 2; ++q) x[2 + D / 2 + q] = S[js][q];
+        x[2 + D / 2 + H / 2] = f2{(float)(p1 - p0), 0.f};
         f2 a1[H / 2], a2[H / 2];
-        mlp2_fwd<C::PHI_IN, H>(PT + A.t_off[fphi] + koff * A.t_sz[fphi], xe, a1, a2);
+        if constexpr (l < 2) {
+          f2 y[1];
+          mlp_fwd<C::LF_IN, H, 2>(PT + A.t_off[C::NPHI + l] + koff * A.t_sz[C::NPHI + l], x, a1, a2, y);
+          float* r0 = reinterpret_cast<float*>(row_ptr(A.state, wr, lane));
+          if constexpr (l == 0) r0[1] = s0.y + y[0].x;                       // theta += L_theta        (main.py:182)
+          else r0[0] = is_gen[n] ? s0.x : s0.x + y[0].x;                     // v += L_v off generators (main.py:184-186)
+        } else {
+          f2 upd_m[D / 2], m_new[D / 2];
+          mlp_fwd<C::LF_IN, H, D>(PT + A.t_off[C::NPHI + 2] + koff * A.t_sz[C::NPHI + 2], x, a1, a2, upd_m);
 #pragma unroll
-        for (int j = 0; j < H / 2; ++j) S[j] += a2[j];
-      }
-      if (A.save && (MULTI || l == 0))
-        store_pairs<H>(A.msg, ((((long long)k * A.G + g) * N + n) * C::NPHI + fphi) * C::HQ, lane, S);
-      x[0] = f2{s0.x, s0.y}; x[1] = f2{s0.z, s0.w};
-#pragma unroll
-      for (int i = 0; i < D / 2; ++i) x[2 + i] = m[i];
-      x[2 + D / 2 + H / 2] = f2{(float)(p1 - p0), 0.f};
-      f2 a1[H / 2], a2[H / 2];
-      if constexpr (l < 2) {
-        f2 y[1];
-        mlp_fwd<C::LF_IN, H, 2>(PT + A.t_off[C::NPHI + l] + koff * A.t_sz[C::NPHI + l], x, a1, a2, y);
-        float* r0 = reinterpret_cast<float*>(row_ptr(A.state, wr, lane));
-        if constexpr (l == 0) r0[1] = s0.y + y[0].x;                       // theta += L_theta        (main.py:182)
-        else r0[0] = is_gen[n] ? s0.x : s0.x + y[0].x;                     // v += L_v off generators (main.py:184-186)
-      } else {
-        f2 upd_m[D / 2], m_new[D / 2];
-        mlp_fwd<C::LF_IN, H, D>(PT + A.t_off[C::NPHI + 2] + koff * A.t_sz[C::NPHI + 2], x, a1, a2, upd_m);
-#pragma unroll
-        for (int i = 0; i < D / 2; ++i) m_new[i] = m[i] + upd_m[i];        // main.py:188
-        store_pairs<D>(A.state, wr + 1, lane, m_new);
-      }
+          for (int i = 0; i < D / 2; ++i) m_new[i] = m[i] + upd_m[i];        // main.py:188
+          store_pairs<D>(A.state, wr + 1, lane, m_new);
+        }
+      });
     };
     for (int u = u0; u < u1; ++u) {
-      const int f = u / N, n = u - f * N;
-      if (f == 0) update_unit(std::integral_constant<int, 0>{}, n);
-      else if (f == 1) update_unit(std::integral_constant<int, 1>{}, n);
-      else update_unit(std::integral_constant<int, 2>{}, n);
+      const int grp = u / N, n = u - grp * N;
+      if (grp == 0) update_unit(std::integral_constant<int, 0>{}, n);
+      else update_unit(std::integral_constant<int, 1>{}, n);
     }
     FSTAMP(0)
     __syncthreads();   // every bus of the 64 grids now has v_{k+1}, theta_{k+1}

@@ -96,9 +96,14 @@ int build(int N, int E, int Gn, const int32_t* src, const int32_t* dst, const in
   std::vector<int32_t> upart(GNS_NPART * (GNS_MAXW + 1)), ppart(GNS_NPART * (GNS_MAXW + 1));
   // forward: (family, bus) units in family-major order (one family's weights stay hot in the scalar cache);
   // packed-FMA instruction estimates of the folded networks: L' ~ 300 (theta, v) / 400 (m), phi' ~ 190 per line
-  std::vector<double> ucost(3 * (size_t)N), pcost(N);
-  for (int f = 0; f < 3; ++f)
-    for (int n = 0; n < N; ++n) ucost[(size_t)f * N + n] = (f == 2 ? 400.0 : 300.0) + 190.0 * (in_ptr[n + 1] - in_ptr[n]);
+  // forward update phase: units u = grp * N + n with grp 0 = (theta, v) families together, grp 1 = m family;
+  // packed-FMA instruction estimates of the folded networks: L' ~ 300 (theta, v) / 400 (m), phi' ~ 190 per line
+  std::vector<double> ucost(2 * (size_t)N), pcost(N);
+  for (int n = 0; n < N; ++n) {
+    const int din = in_ptr[n + 1] - in_ptr[n];
+    ucost[n] = 600.0 + 380.0 * din;
+    ucost[(size_t)N + n] = 400.0 + 190.0 * din;
+  }
   // (waves of a workgroup do not run at equal speed: VALU issue favours the older waves of a SIMD, so the youngest four
   //  finish last whatever they are given; weighting their share down was measured slower, the SIMD total is what counts)
   for (int n = 0; n < N; ++n) pcost[n] = 60.0 + 130.0 * (in_ptr[n + 1] - in_ptr[n]) + 80.0 * (out_ptr[n + 1] - out_ptr[n]);

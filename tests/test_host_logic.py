@@ -111,7 +111,7 @@ def test_topology_blob(case):
     for wi, W in enumerate((1, 2, 4, 8, 16)):
         up = blob[blob[H['UPART']] + wi * 17: blob[H['UPART']] + wi * 17 + 17]
         pp = blob[blob[H['PPART']] + wi * 17: blob[H['PPART']] + wi * 17 + 17]
-        assert up[0] == 0 and up[W] == 3 * N and np.all(np.diff(up) >= 0)        # (family, bus) units of the forward update phase
+        assert up[0] == 0 and up[W] == 2 * N and np.all(np.diff(up) >= 0)        # (family group, bus) units of the forward update phase
         assert pp[0] == 0 and pp[W] == N and np.all(np.diff(pp) >= 0)
 
 
