@@ -510,6 +510,7 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
             dw_accumulate<C::LF_IN, H, OUT, OUTP>(rec, lane, TL, accL, x, a1, a2, g1, g2, g3);
           }
           if constexpr (MULTI) {
+            if (p0 < p1) load_pairs<D>(A.state, rr + 1, lane, m);   // re-read (cache-hot) instead of keeping 20 registers live across L'
 #ifdef GNS_ABLATE_MSGBWD
             for (int p = p0; p < p0; ++p) {
 #else
