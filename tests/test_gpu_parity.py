@@ -179,3 +179,32 @@ def test_more_groups_than_backward_workgroups():
         t_h.sum().backward()
         parts.append(torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone())
     assert_close(((parts[0] + parts[1]) / bt).cpu(), g_all.cpu(), 2e-5, abs_floor=1e-7, what='20000-grid gradient')
+
+
+def test_config5_shape_case300_K10_batched():
+    """BASELINE config 5 shape (case300, K=10, multiple_phi) at a batch spanning several wave-groups, forward and
+    gradient against the CPU oracle on a sample (autograd through the oracle costs ~1 s per grid at this size)."""
+    import opf_graph_neural_solver_amd as amd
+    from oracle import gns_oracle as orc
+    torch.manual_seed(5)
+    m = amd.GNS(20, 10, 10, 0.9, True).cuda()
+    bt = 200
+    bu, li, ge = amd.synth.synth_grids(300, bt, seed=12)
+    v, th, tot, last = m(bu.cuda(), li.cuda(), ge.cuda())
+    w = torch.zeros(bt)
+    sample = [0, 63, 64, 199]
+    w[sample] = 1.0
+    (tot * w.cuda()).sum().backward()
+    grad = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).cpu()
+    flat = m.flat_parameters().detach().cpu()
+    fo = flat.clone().requires_grad_(True)
+    po = orc.unflatten_params(fo, 20, 10, 10, True)
+    acc = 0.
+    for b in sample:
+        vo, tho, toto, lasto = orc.gns_forward(po, bu[b], li[b], ge[b], latent_dim=20, K=10, gamma=0.9, multiple_phi=True)
+        assert_close(v[b].detach().cpu(), vo.detach(), REL, what=f'v[{b}]')
+        assert_close(th[b].detach().cpu(), tho.detach(), REL, what=f'theta[{b}]')
+        assert_close(last[b].detach().cpu(), lasto.detach(), REL, what=f'last[{b}]')
+        acc = acc + toto
+    acc.backward()
+    assert_close(grad, fo.grad, 5e-5, abs_floor=1e-6, what='grad case300 K=10')
