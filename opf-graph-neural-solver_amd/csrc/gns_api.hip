@@ -124,7 +124,7 @@ extern "C" int gns_forward(const gns_config* cfg, const void* topo_dev, const fl
   A.v_out = v; A.theta_out = theta; A.total_out = total_loss; A.last_out = last_loss;
   for (int i = 0; i < fam.nfam; ++i) { A.t_off[i] = fam.t_off[i]; A.t_sz[i] = fam.t_sz[i]; }
   for (int k = 0; k < K; ++k) A.gw[k] = (float)std::pow((double)cfg->gamma, (double)(K - k));   // main.py:198
-  A.Bt = Bt; A.G = L.groups; A.N = N; A.E = E; A.K = K; A.save = save_state ? 1 : 0; A.zero = 0;
+  A.Bt = Bt; A.G = L.groups; A.N = N; A.E = E; A.K = K; A.save = save_state ? 1 : 0;
   int waves = GNS_FWD_THREADS / 64;
   if (const char* e = std::getenv("GNS_FWD_WAVES")) { int w = std::atoi(e); if (gns_part_index(w) >= 0 && w * 64 <= GNS_FWD_MAX_THREADS) waves = w; }
   A.part_idx = gns_part_index(waves);

@@ -30,9 +30,6 @@ struct RecLay {
 #define GNS_REC_ROWS 32
 constexpr int gns_cmax(int a, int b) { return a > b ? a : b; }
 
-template <int N, int I>
-__device__ __forceinline__ float pick(const float (&x)[N]) { return x[I]; }
-
 template <int IN, int H, int OUT, int OUTP>
 __device__ __forceinline__ void rec_write(float* rec, int row, const f2 (&x)[(IN + 1) / 2], const f2 (&a1)[H / 2], const f2 (&a2)[H / 2],
                                           const f2 (&g1)[H / 2], const f2 (&g2)[H / 2], const f2 (&g3)[OUTP / 2]) {

@@ -262,27 +262,3 @@ __device__ __forceinline__ void store_pairs(float* base, long long row, int lane
     *row_ptr(base, row + q, lane) = t;
   });
 }
-
-template <int D>
-__device__ __forceinline__ void load_vec(const float* base, long long row, int lane, float (&m)[D]) {
-  static_for<0, (D + 3) / 4>([&](auto q_) {
-    constexpr int q = decltype(q_)::value;
-    const f4 t = *row_ptr(base, row + q, lane);
-    if constexpr (4 * q + 0 < D) m[4 * q + 0] = t.x;
-    if constexpr (4 * q + 1 < D) m[4 * q + 1] = t.y;
-    if constexpr (4 * q + 2 < D) m[4 * q + 2] = t.z;
-    if constexpr (4 * q + 3 < D) m[4 * q + 3] = t.w;
-  });
-}
-template <int D>
-__device__ __forceinline__ void store_vec(float* base, long long row, int lane, const float (&m)[D]) {
-  static_for<0, (D + 3) / 4>([&](auto q_) {
-    constexpr int q = decltype(q_)::value;
-    f4 t = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (4 * q + 0 < D) t.x = m[4 * q + 0];
-    if constexpr (4 * q + 1 < D) t.y = m[4 * q + 1];
-    if constexpr (4 * q + 2 < D) t.z = m[4 * q + 2];
-    if constexpr (4 * q + 3 < D) t.w = m[4 * q + 3];
-    *row_ptr(base, row + q, lane) = t;
-  });
-}

@@ -36,7 +36,7 @@ struct GnsFwdArgs {
   long long t_off[6], t_sz[6];
   float gw[GNS_MAX_K];    // gamma^(K-k) rounded to fp32 from a double, like the reference's python float
   long long Bt, G;
-  int N, E, K, save, zero, part_idx;
+  int N, E, K, save, part_idx;
 };
 
 struct GnsBwdArgs {

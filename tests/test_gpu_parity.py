@@ -208,3 +208,26 @@ def test_config5_shape_case300_K10_batched():
         acc = acc + toto
     acc.backward()
     assert_close(grad, fo.grad, 5e-5, abs_floor=1e-6, what='grad case300 K=10')
+
+
+def test_c_abi_calls_are_graph_capturable():
+    """include/gns_hip.h promises no allocation / synchronisation / host copies inside gns_forward: capture an inference
+    call into a HIP graph (torch.cuda.graph), replay it on new inputs and compare with the eager result."""
+    import opf_graph_neural_solver_amd as amd
+    torch.manual_seed(2)
+    m = amd.GNS(20, 10, 4, 0.9, True).cuda()
+    m.topology_check = 'first'
+    bu, li, ge = amd.synth.synth_grids(30, 320, seed=1, device='cuda')
+    bu2, li2, ge2 = amd.synth.synth_grids(30, 320, seed=2, device='cuda')
+    sb, sl, sg = bu.clone(), li.clone(), ge.clone()
+    with torch.no_grad():
+        m(sb, sl, sg)                                  # warm-up: topology blob, library load
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = m(sb, sl, sg)
+        sb.copy_(bu2); sl.copy_(li2); sg.copy_(ge2)
+        graph.replay()
+        torch.cuda.synchronize()
+        ref = m(bu2, li2, ge2)
+    assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]) and torch.equal(out[2], ref[2])
