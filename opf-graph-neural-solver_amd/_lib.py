@@ -27,6 +27,14 @@ def load_library():
     if _LIB is not None:
         return _LIB
     path = library_path()
+    if not os.path.exists(path) and not os.environ.get('GNS_LIB') and os.environ.get('GNS_NO_AUTOBUILD') != '1':
+        # a source-only checkout: build in-tree once (hipcc cross-compiles for gfx950; ~1 minute); never a fallback path
+        import shutil
+        import subprocess
+        if shutil.which('make') and (shutil.which('hipcc') or os.path.exists('/opt/rocm/bin/hipcc')):
+            env = dict(os.environ, PATH=os.environ.get('PATH', '') + ':/opt/rocm/bin')
+            subprocess.run(['make', '-C', os.path.join(_HERE, 'csrc'), '-j4'], check=False, env=env,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     if not os.path.exists(path):
         raise OSError(f'{path} not found: build it with `make -C {os.path.join(_HERE, "csrc")}` '
                       '(hipcc --offload-arch=gfx950) or `python -c "import __graft_entry__ as g; g.build()"`. '
