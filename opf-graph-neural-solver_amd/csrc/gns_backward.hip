@@ -256,8 +256,132 @@ __device__ __forceinline__ void zero_acc(f2 (&acc)[4][2]) {
   for (int a = 0; a < 4; ++a) { acc[a][0] = f2{0.f, 0.f}; acc[a][1] = f2{0.f, 0.f}; }
 }
 
+// ---- weight-gradient engines: one object per (network, family sweep); VALU = the shipped path --------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int IN, int H, int OUT, int OUTP, bool MFMA>
+struct LEngine;    // three-layer block (L')
+template <int IN, int H, bool MFMA>
+struct PEngine;    // two-layer block (phi')
+
+template <int IN, int H, int OUT, int OUTP>
+struct LEngine<IN, H, OUT, OUTP, false> {
+  DwTile T;
+  f2 acc[4][2];
+  __device__ __forceinline__ void init(int lane) { T = dw_tile<IN, H, OUT>(lane); zero_acc(acc); }
+  __device__ __forceinline__ void accumulate(float* rec, int lane, const f2 (&x)[(IN + 1) / 2], const f2 (&a1)[H / 2], const f2 (&a2)[H / 2],
+                                             const f2 (&g1)[H / 2], const f2 (&g2)[H / 2], const f2 (&g3)[OUTP / 2]) {
+    dw_accumulate<IN, H, OUT, OUTP>(rec, lane, T, acc, x, a1, a2, g1, g2, g3);
+  }
+  __device__ __forceinline__ void flush(int lane, float* slab_blk) { dw_flush<IN, H, OUT>(lane, T, acc, slab_blk); }
+};
+template <int IN, int H>
+struct PEngine<IN, H, false> {
+  DwTile T;
+  f2 acc[4][2];
+  __device__ __forceinline__ void init(int lane) { T = dw_tile2<IN, H>(lane); zero_acc(acc); }
+  __device__ __forceinline__ void accumulate(float* rec, int lane, const f2 (&x)[(IN + 1) / 2], const f2 (&a1)[H / 2],
+                                             const f2 (&g1)[H / 2], const f2 (&g2)[H / 2]) {
+    dw_accumulate2<IN, H>(rec, lane, T, acc, x, a1, g1, g2);
+  }
+  __device__ __forceinline__ void flush(int lane, float* slab_blk) { dw_flush2<IN, H>(lane, T, acc, slab_blk); }
+};
+
+// EXPERIMENT (off unless GNS_DW_MFMA=1; north_star asks for explicit FMA loops): the same contraction on the matrix
+// pipe with v_mfma_f32_16x16x4_f32 - exact fp32, the k index runs over the grids (rows of the LDS record buffer).
+// Lane l feeds A[c = l&15][k = l>>4] = g[row 4kk + (l>>4)][cbase + (l&15)] and B[k][i = l&15] = input[row][ibase + (l&15)],
+// and holds D[c = 4*(l>>4) + reg][i = l&15].  Columns past a field's width read the neighbouring field: those
+// products only reach D entries that the flush ignores.
+template <int IN, int H, int OUT, int OUTP>
+struct LEngine<IN, H, OUT, OUTP, true> {
+  using R = RecLay<IN, H, OUT>;
+  static constexpr int NB1 = (R::XP + 15) / 16, NA4 = (R::GP + 15) / 16, NTL = NB1 + 1 + NA4;
+  f32x4 Dacc[NTL];
+  __device__ __forceinline__ void init(int) {
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) Dacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  __device__ __forceinline__ void accumulate(float* rec, int lane, const f2 (&x)[(IN + 1) / 2], const f2 (&a1)[H / 2], const f2 (&a2)[H / 2],
+                                             const f2 (&g1)[H / 2], const f2 (&g2)[H / 2], const f2 (&g3)[OUTP / 2]) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if ((lane >> 5) == half) rec_write<IN, H, OUT, OUTP>(rec, lane & 31, x, a1, a2, g1, g2, g3);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const float* base = rec + (lane >> 4) * R::RS + (lane & 15);
+#pragma unroll 2
+      for (int kk = 0; kk < GNS_REC_ROWS / 4; ++kk) {
+        const float* b = base + kk * 4 * R::RS;
+        const float ag1 = b[R::oG1], ag2 = b[R::oG2], ba1 = b[R::oA1], ba2 = b[R::oA2];
+        static_for<0, NB1>([&](auto t_) { constexpr int t = decltype(t_)::value; Dacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag1, b[R::oX + 16 * t], Dacc[t], 0, 0, 0); });
+        Dacc[NB1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag2, ba1, Dacc[NB1], 0, 0, 0);
+        static_for<0, NA4>([&](auto t_) { constexpr int t = decltype(t_)::value; Dacc[NB1 + 1 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[R::oG3 + 16 * t], ba2, Dacc[NB1 + 1 + t], 0, 0, 0); });
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __device__ __forceinline__ void flush(int lane, float* slab_blk) {
+    constexpr int ob1 = IN * H, oW2 = ob1 + H, ob2 = oW2 + H * H, oW4 = ob2 + H, ob4 = oW4 + OUT * H;
+    const int cl = 4 * (lane >> 4), il = lane & 15;
+    static_for<0, NTL>([&](auto t_) {
+      constexpr int t = decltype(t_)::value;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = cl + r;
+        int idx = -1;
+        if constexpr (t < NB1) { const int i = 16 * t + il; if (c < H) idx = (i < IN) ? c * IN + i : (i == IN ? ob1 + c : -1); }
+        else if constexpr (t == NB1) { if (c < H) idx = (il < H) ? oW2 + c * H + il : (il == H ? ob2 + c : -1); }
+        else { const int j = 16 * (t - NB1 - 1) + c; if (j < OUT) idx = (il < H) ? oW4 + j * H + il : (il == H ? ob4 + j : -1); }
+        if (idx >= 0) slab_blk[idx] += Dacc[t][r];
+      }
+    });
+  }
+};
+template <int IN, int H>
+struct PEngine<IN, H, true> {
+  using R = RecLay2<IN, H>;
+  static constexpr int NB1 = (R::XP + 15) / 16, NTL = NB1 + 1;
+  f32x4 Dacc[NTL];
+  __device__ __forceinline__ void init(int) {
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) Dacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  __device__ __forceinline__ void accumulate(float* rec, int lane, const f2 (&x)[(IN + 1) / 2], const f2 (&a1)[H / 2],
+                                             const f2 (&g1)[H / 2], const f2 (&g2)[H / 2]) {
+    rec_write2<IN, H>(rec, lane, x, a1, g1, g2);                 // all 64 records at once
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const float* base = rec + (lane >> 4) * R::RS + (lane & 15);
+#pragma unroll 2
+    for (int kk = 0; kk < 2 * GNS_REC_ROWS / 4; ++kk) {
+      const float* b = base + kk * 4 * R::RS;
+      const float ag1 = b[R::oG1], ag2 = b[R::oG2], ba1 = b[R::oA1];
+      static_for<0, NB1>([&](auto t_) { constexpr int t = decltype(t_)::value; Dacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag1, b[R::oX + 16 * t], Dacc[t], 0, 0, 0); });
+      Dacc[NB1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag2, ba1, Dacc[NB1], 0, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  __device__ __forceinline__ void flush(int lane, float* slab_blk) {
+    constexpr int ob1 = IN * H, oW2 = ob1 + H, ob2 = oW2 + H * H;
+    const int cl = 4 * (lane >> 4), il = lane & 15;
+    static_for<0, NTL>([&](auto t_) {
+      constexpr int t = decltype(t_)::value;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = cl + r;
+        int idx = -1;
+        if constexpr (t < NB1) { const int i = 16 * t + il; if (c < H) idx = (i < IN) ? c * IN + i : (i == IN ? ob1 + c : -1); }
+        else { if (c < H) idx = (il < H) ? oW2 + c * H + il : (il == H ? ob2 + c : -1); }
+        if (idx >= 0) slab_blk[idx] += Dacc[t][r];
+      }
+    });
+  }
+};
+
 // ------------------------------------------------------------------------------------------------
-template <int D, int H, bool MULTI>
+template <int D, int H, bool MULTI, bool MFMA>
 __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArgs A) {
   using C = GnsDims<D, H, MULTI>;
   constexpr int RB = C::RB;
@@ -280,7 +404,7 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
   const float* IN = A.in;
 
   constexpr int RECF = gns_cmax(GNS_REC_ROWS * gns_cmax(RecLay<C::LF_IN, H, D>::RS, RecLay<C::LF_IN, H, 1>::RS),
-                                2 * GNS_REC_ROWS * RecLay2<C::PHI_IN, H>::RS);
+                                2 * GNS_REC_ROWS * RecLay2<C::PHI_IN, H>::RS) + 32;   // +32: the MFMA variant reads 16-wide column blocks
   __shared__ __attribute__((aligned(16))) float rec_all[W][RECF];
   __shared__ float red[2][W][GNS_LANES];
   float* rec = rec_all[wave];
@@ -459,10 +583,9 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
         constexpr int OUT = (l == 2) ? D : 1, OUTP = OUT + (OUT & 1);
         // after the last step nothing reads m_K: L_m.{K-1} / phi_m.{K-1} get no gradient (reference: .grad is None)
         if (l == 2 && k == K - 1) return;
-        const DwTile TL = dw_tile<C::LF_IN, H, OUT>(lane);
-        const DwTile TP = dw_tile2<C::PHI_IN, H>(lane);
-        f2 accL[4][2], accP[4][2];
-        zero_acc(accL); zero_acc(accP);
+        LEngine<C::LF_IN, H, OUT, OUTP, MFMA> engL;
+        PEngine<C::PHI_IN, H, MFMA> engP;
+        engL.init(lane); engP.init(lane);
         for (int n = n0; n < n1; ++n) {
           const long long ar = adj_row(n), rr = state_row(k, n);
           const f4 a0 = *row_ptr(A.adj, ar, lane);
@@ -504,7 +627,7 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
             }
             mlp_bwd<C::LF_IN, H, OUTP, 2 * XL, true>(PN + A.n_off[C::NPHI + l] + koff * A.n_sz[C::NPHI + l], a1, a2, g3, g2, g1, gx);
             xsum.x += gx[0].x; xsum.y += gx[0].y; xsum.z += gx[1].x;
-            dw_accumulate<C::LF_IN, H, OUT, OUTP>(rec, lane, TL, accL, x, a1, a2, g1, g2, g3);
+            engL.accumulate(rec, lane, x, a1, a2, g1, g2, g3);
           }
           if constexpr (MULTI) {
             if (p0 < p1) load_pairs<D>(A.state, rr + 1, lane, m);   // re-read (cache-hot) instead of keeping 20 registers live across L'
@@ -518,7 +641,7 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
               mlp2_fwd<C::PHI_IN, H>(PT + A.t_off[fphi] + koff * A.t_sz[fphi], xe, a1, a2);
               // x = [m(dst) | ...] (main.py:155): the m part of the input adjoint goes straight into macc
               mlp2_bwd<C::PHI_IN, H, D, true>(PN + A.n_off[fphi] + koff * A.n_sz[fphi], a1, a2, gS, g2, g1, macc);
-              dw_accumulate2<C::PHI_IN, H>(rec, lane, TP, accP, xe, a1, g1, g2);
+              engP.accumulate(rec, lane, xe, a1, g1, g2);
             }
           } else {
             store_pairs<H>(A.adj, ar + 2, lane, gS);
@@ -526,14 +649,13 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
           *row_ptr(A.adj, ar + 1, lane) = xsum;
           store_pairs<D>(A.adj, ar + RM, lane, macc);
         }
-        dw_flush<C::LF_IN, H, OUT>(lane, TL, accL, slab + A.g_off[C::NPHI + l] + koff * A.g_sz[C::NPHI + l]);
-        if constexpr (MULTI) dw_flush2<C::PHI_IN, H>(lane, TP, accP, slab + A.g_off[fphi] + koff * A.g_sz[fphi]);
+        engL.flush(lane, slab + A.g_off[C::NPHI + l] + koff * A.g_sz[C::NPHI + l]);
+        if constexpr (MULTI) engP.flush(lane, slab + A.g_off[fphi] + koff * A.g_sz[fphi]);
         STAMP(5 + l)
       });
       if constexpr (!MULTI) {                                  // the single phi: its hidden-sum adjoint is the sum over the three L nets
-        const DwTile TP = dw_tile2<C::PHI_IN, H>(lane);
-        f2 accP[4][2];
-        zero_acc(accP);
+        PEngine<C::PHI_IN, H, MFMA> engP;
+        engP.init(lane);
         for (int n = n0; n < n1; ++n) {
           const long long ar = adj_row(n), rr = state_row(k, n);
           f2 m[D / 2], macc[D / 2], gS[H / 2];
@@ -546,11 +668,11 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
             edge_input(p, m, xe);
             mlp2_fwd<C::PHI_IN, H>(PT + A.t_off[0] + koff * A.t_sz[0], xe, a1, a2);
             mlp2_bwd<C::PHI_IN, H, D, true>(PN + A.n_off[0] + koff * A.n_sz[0], a1, a2, gS, g2, g1, macc);
-            dw_accumulate2<C::PHI_IN, H>(rec, lane, TP, accP, xe, a1, g1, g2);
+            engP.accumulate(rec, lane, xe, a1, g1, g2);
           }
           store_pairs<D>(A.adj, ar + RM, lane, macc);
         }
-        dw_flush2<C::PHI_IN, H>(lane, TP, accP, slab + A.g_off[0] + koff * A.g_sz[0]);
+        engP.flush(lane, slab + A.g_off[0] + koff * A.g_sz[0]);
       }
       STAMP(8)
     }
@@ -627,16 +749,18 @@ __global__ void gns_unfold_kernel(const float* __restrict__ gf, const float* __r
   for (int e = threadIdx.x; e < rest; e += blockDim.x) dst[H * IN + e] += g[H * INF + e];
 }
 
-template <int D, int H, bool MULTI>
+template <int D, int H, bool MULTI, bool MFMA>
 static int launch_backward_t(const GnsBwdArgs& A, int blocks, hipStream_t st) {
-  hipLaunchKernelGGL((gns_backward_kernel<D, H, MULTI>), dim3(blocks), dim3(GNS_BWD_THREADS), 0, st, A);
+  hipLaunchKernelGGL((gns_backward_kernel<D, H, MULTI, MFMA>), dim3(blocks), dim3(GNS_BWD_THREADS), 0, st, A);
   return hipGetLastError() == hipSuccess ? GNS_OK : GNS_ELAUNCH;
 }
 
-int gns_launch_backward(int d, int h, int multi, const GnsBwdArgs& A, int blocks, hipStream_t st) {
-#define GNS_CASE(DD, HH)                                                                      \
-  if (d == DD && h == HH) return multi ? launch_backward_t<DD, HH, true>(A, blocks, st)       \
-                                       : launch_backward_t<DD, HH, false>(A, blocks, st);
+int gns_launch_backward(int d, int h, int multi, int mfma, const GnsBwdArgs& A, int blocks, hipStream_t st) {
+#define GNS_CASE(DD, HH)                                                                                      \
+  if (d == DD && h == HH) {                                                                                   \
+    if (mfma) return multi ? launch_backward_t<DD, HH, true, true>(A, blocks, st) : launch_backward_t<DD, HH, false, true>(A, blocks, st);   \
+    return multi ? launch_backward_t<DD, HH, true, false>(A, blocks, st) : launch_backward_t<DD, HH, false, false>(A, blocks, st);          \
+  }
   GNS_FOR_EACH_DIMS(GNS_CASE)
 #undef GNS_CASE
   return GNS_EUNSUPPORTED;
