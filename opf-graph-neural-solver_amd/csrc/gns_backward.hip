@@ -309,14 +309,26 @@ struct LEngine<IN, H, OUT, OUTP, true> {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       const float* base = rec + (lane >> 4) * R::RS + (lane & 15);
-#pragma unroll 2
-      for (int kk = 0; kk < GNS_REC_ROWS / 4; ++kk) {
+      // operands of step kk+1 are read while the matrix pipe works on step kk
+      constexpr int NOP = 4 + NB1 + NA4;
+      float op[2][NOP];
+      auto fetch = [&](float (&o)[NOP], int kk) {
         const float* b = base + kk * 4 * R::RS;
-        const float ag1 = b[R::oG1], ag2 = b[R::oG2], ba1 = b[R::oA1], ba2 = b[R::oA2];
-        static_for<0, NB1>([&](auto t_) { constexpr int t = decltype(t_)::value; Dacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag1, b[R::oX + 16 * t], Dacc[t], 0, 0, 0); });
-        Dacc[NB1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag2, ba1, Dacc[NB1], 0, 0, 0);
-        static_for<0, NA4>([&](auto t_) { constexpr int t = decltype(t_)::value; Dacc[NB1 + 1 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[R::oG3 + 16 * t], ba2, Dacc[NB1 + 1 + t], 0, 0, 0); });
-      }
+        o[0] = b[R::oG1]; o[1] = b[R::oG2]; o[2] = b[R::oA1]; o[3] = b[R::oA2];
+        static_for<0, NB1>([&](auto t_) { constexpr int t = decltype(t_)::value; o[4 + t] = b[R::oX + 16 * t]; });
+        static_for<0, NA4>([&](auto t_) { constexpr int t = decltype(t_)::value; o[4 + NB1 + t] = b[R::oG3 + 16 * t]; });
+      };
+      fetch(op[0], 0);
+      static_for<0, GNS_REC_ROWS / 4>([&](auto kk_) {
+        constexpr int kk = decltype(kk_)::value;
+        if constexpr (kk + 1 < GNS_REC_ROWS / 4) fetch(op[(kk + 1) & 1], kk + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const float (&o)[NOP] = op[kk & 1];
+        static_for<0, NB1>([&](auto t_) { constexpr int t = decltype(t_)::value; Dacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(o[0], o[4 + t], Dacc[t], 0, 0, 0); });
+        Dacc[NB1] = __builtin_amdgcn_mfma_f32_16x16x4f32(o[1], o[2], Dacc[NB1], 0, 0, 0);
+        static_for<0, NA4>([&](auto t_) { constexpr int t = decltype(t_)::value; Dacc[NB1 + 1 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(o[4 + NB1 + t], o[3], Dacc[NB1 + 1 + t], 0, 0, 0); });
+        __builtin_amdgcn_sched_barrier(0);
+      });
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
@@ -353,13 +365,23 @@ struct PEngine<IN, H, true> {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const float* base = rec + (lane >> 4) * R::RS + (lane & 15);
-#pragma unroll 2
-    for (int kk = 0; kk < 2 * GNS_REC_ROWS / 4; ++kk) {
+    constexpr int NOP = 3 + NB1;
+    float op[2][NOP];
+    auto fetch = [&](float (&o)[NOP], int kk) {
       const float* b = base + kk * 4 * R::RS;
-      const float ag1 = b[R::oG1], ag2 = b[R::oG2], ba1 = b[R::oA1];
-      static_for<0, NB1>([&](auto t_) { constexpr int t = decltype(t_)::value; Dacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag1, b[R::oX + 16 * t], Dacc[t], 0, 0, 0); });
-      Dacc[NB1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag2, ba1, Dacc[NB1], 0, 0, 0);
-    }
+      o[0] = b[R::oG1]; o[1] = b[R::oG2]; o[2] = b[R::oA1];
+      static_for<0, NB1>([&](auto t_) { constexpr int t = decltype(t_)::value; o[3 + t] = b[R::oX + 16 * t]; });
+    };
+    fetch(op[0], 0);
+    static_for<0, 2 * GNS_REC_ROWS / 4>([&](auto kk_) {
+      constexpr int kk = decltype(kk_)::value;
+      if constexpr (kk + 1 < 2 * GNS_REC_ROWS / 4) fetch(op[(kk + 1) & 1], kk + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const float (&o)[NOP] = op[kk & 1];
+      static_for<0, NB1>([&](auto t_) { constexpr int t = decltype(t_)::value; Dacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(o[0], o[3 + t], Dacc[t], 0, 0, 0); });
+      Dacc[NB1] = __builtin_amdgcn_mfma_f32_16x16x4f32(o[1], o[2], Dacc[NB1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
