@@ -117,7 +117,7 @@ def main():
     torch.manual_seed(0)                       # identical replicas on every rank
     model = amd.GNS(latent_dim=D, hidden_dim=H, K=K, gamma=GAMMA, multiple_phi=MULTI).to(dev)
     model.topology_check = 'first'             # id columns are verified once per case, not on every step
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)    # the reference's optimiser (GNS/main.py:243)
+    opt = amd.training.make_optimizer(model)               # the reference's optimiser: Adam, lr 1e-3 (GNS/main.py:241-243)
     bt = a.batch_per_gpu
     buses, lines, gens = amd.synth.synth_grids(CASE, bt, seed=1234 + rank, device=dev)   # resident before timing
     Bc, Lc, Gc = amd.get_BLG()

@@ -170,9 +170,10 @@ extern "C" int gns_backward(const gns_config* cfg, const void* topo_dev, const f
   A.Bt = Bt; A.G = B.groups; A.slab_floats = B.slab_floats; A.N = N; A.E = E; A.K = K;
   A.part_idx = gns_part_index(GNS_BWD_WAVES);
   prof_mark(1, true, st);
-  // GNS_DW_MFMA=1 selects the experimental matrix-pipe weight-gradient contraction (see gns_backward.hip); default: packed FMA
+  // The weight-gradient contraction over the grids runs on the matrix pipe (exact fp32) unless GNS_DW_MFMA=0 asks for
+  // the packed-FMA register tiles; both are parity-tested (gns_backward.hip, "weight-gradient engines").
   const char* mf = std::getenv("GNS_DW_MFMA");
-  rc = gns_launch_backward(d, h, cfg->multiple_phi, (mf && mf[0] == '1') ? 1 : 0, A, blocks, st);
+  rc = gns_launch_backward(d, h, cfg->multiple_phi, (mf && mf[0] == '0') ? 0 : 1, A, blocks, st);
   prof_mark(1, false, st);
   if (rc != GNS_OK) return rc;
   return gns_launch_reduce(A.slab, (float*)(bw + B.off_part), (float*)(bw + B.off_tmp), params, grad_params, nslab, B.slab_floats,

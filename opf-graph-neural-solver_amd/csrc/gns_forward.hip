@@ -78,58 +78,87 @@ __global__ void gns_pack_params_kernel(const float* __restrict__ flat, float* __
 // and the batch-invariant pieces of GNS.forward's prologue (main.py:144-152) and of the physics
 // (y = 1/sqrt(r^2+x^2), main.py:38,87; the bus-id-as-line-index gathers of y, tau, shift, b).
 // ------------------------------------------------------------------------------------------------
+// One wave per unit, units of one kind per workgroup: a bus (its 3 rows), a line in dst order (its 3 rows), four
+// lines in src order (1 row each), the per-grid sums.  Lane = grid, so every load of a wave touches 64 different cache
+// lines and the kernel is latency-bound: a unit issues all its loads before it uses any, and the [.,6] / [.,7] tables
+// (rows only 4-byte aligned) are read 2-4 columns at a time (gfx950 global loads need dword alignment only).
 __global__ void gns_pack_inputs_kernel(const int* __restrict__ topo, const float* __restrict__ buses,
                                        const float* __restrict__ lines, const float* __restrict__ gens,
-                                       float* __restrict__ out, int N, int E, int Gn, long long Bt, long long rows) {
-  const int lane = threadIdx.x & 63;
-  const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const long long g = blockIdx.y;
-  if (row >= rows) return;
+                                       float* __restrict__ out, int N, int E, int Gn, long long Bt, long long rows, long long groups) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
+  // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2; every workgroup of one group of 64 grids
+  // re-reads the same 0.6 MB of input, so a group is kept on one XCD: linear id -> (xcd, j), group = 8 (j / chunks) + xcd.
+  const int cb = (N + W - 1) / W, ci = (E + W - 1) / W, co = ((E + 3) / 4 + W - 1) / W;
+  const long long chunks = cb + ci + co + 1;
+  const long long lin = blockIdx.x, j = lin >> 3;
+  const long long g = (j / chunks) * 8 + (lin & 7);
+  const int c = (int)(j % chunks);
+  if (g >= groups) return;
   long long b = g * GNS_LANES + lane;
   if (b >= Bt) b = Bt - 1;               // dead lanes replay the last grid; their results are never stored
   const float* bu = buses + b * (long long)N * 6;
   const float* li = lines + b * (long long)E * 7;
   const float* ge = gens + b * (long long)Gn * 7;
-  f4 o = {0.f, 0.f, 0.f, 0.f};
-  auto yline = [&](int l) {              // main.py:38: 1 / sqrt(r^2 + x^2), each op rounded like torch does
-    float r = li[l * 7 + 2], x = li[l * 7 + 3];
+  struct __attribute__((packed, aligned(4))) U4 { float x, y, z, w; };
+  struct __attribute__((packed, aligned(4))) U2 { float x, y; };
+  auto ld4 = [](const float* p) { const U4 u = *reinterpret_cast<const U4*>(p); return f4{u.x, u.y, u.z, u.w}; };
+  auto ld2 = [](const float* p) { const U2 u = *reinterpret_cast<const U2*>(p); return f2{u.x, u.y}; };
+  auto yof = [](float r, float x) {      // main.py:38: 1 / sqrt(r^2 + x^2), each op rounded like torch does
     return __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(__fmul_rn(r, r), __fmul_rn(x, x))));
   };
-  if (row < 3LL * N) {
-    const int n = (int)(row / 3), which = (int)(row % 3);
-    const float Pd = bu[n * 6 + 2], Qd = bu[n * 6 + 3], Gs = bu[n * 6 + 4], Bs = bu[n * 6 + 5];
-    if (which == 0) {
-      o = f4{Pd, Qd, Gs, Bs};
-    } else {
-      float pmin = 0.f, pset = 0.f, pmax = 0.f, vg = 0.f, pg = 0.f, qg = 0.f;
-      const int g0 = topo[topo[TH_GEN_PTR] + n], g1 = topo[topo[TH_GEN_PTR] + n + 1];
-      for (int q = g0; q < g1; ++q) {
-        const float* r = ge + topo[topo[TH_GEN_IDX] + q] * 7;     // (bus_i,Pmax,Pmin,Pg_set,vg,qg,Pg) utils.py:9
-        pmax += r[1]; pmin += r[2]; pset += r[3]; vg += r[4]; qg += r[5]; pg += r[6];
-      }
-      const float v0 = (vg == 0.f) ? 1.f : vg;                    // main.py:146-147
-      if (which == 1) o = f4{pmin, pset, pmax, v0};
-      else o = f4{__fsub_rn(__fsub_rn(pg, Pd), __fmul_rn(Gs, __fmul_rn(v0, v0))),     // main.py:150
-                  __fadd_rn(__fsub_rn(qg, Qd), __fmul_rn(Bs, __fmul_rn(v0, v0))), 0.f, 0.f};  // main.py:152
+  float* og = out + g * rows * (GNS_LANES * 4);
+  auto put = [&](long long row, const f4& o) { *row_ptr(og, row, lane) = o; };
+
+  if (c < cb) {                                                     // ---- bus n: rows 3n .. 3n+2
+    const int n = c * W + wave;
+    if (n >= N) return;
+    const f4 bq = ld4(bu + n * 6 + 2);                              // Pd, Qd, Gs, Bs
+    float pmin = 0.f, pset = 0.f, pmax = 0.f, vg = 0.f, pg = 0.f, qg = 0.f;
+    const int g0 = topo[topo[TH_GEN_PTR] + n], g1 = topo[topo[TH_GEN_PTR] + n + 1];
+    for (int q = g0; q < g1; ++q) {
+      const float* r = ge + topo[topo[TH_GEN_IDX] + q] * 7;         // (bus_i,Pmax,Pmin,Pg_set,vg,qg,Pg) utils.py:9
+      const f4 ra = ld4(r + 1);
+      const f2 rb = ld2(r + 5);
+      pmax += ra.x; pmin += ra.y; pset += ra.z; vg += ra.w; qg += rb.x; pg += rb.y;
     }
-  } else if (row < 3LL * N + 3LL * E) {
-    const long long r = row - 3LL * N;
-    const int p = (int)(r / 3), which = (int)(r % 3);
+    const float v0 = (vg == 0.f) ? 1.f : vg;                        // main.py:146-147
+    put(3LL * n, bq);
+    put(3LL * n + 1, f4{pmin, pset, pmax, v0});
+    put(3LL * n + 2, f4{__fsub_rn(__fsub_rn(pg, bq.x), __fmul_rn(bq.z, __fmul_rn(v0, v0))),          // main.py:150
+                        __fadd_rn(__fsub_rn(qg, bq.y), __fmul_rn(bq.w, __fmul_rn(v0, v0))), 0.f, 0.f});   // main.py:152
+  } else if (c < cb + ci) {                                         // ---- line p in dst order: rows 3N + 3p ..
+    const int p = (c - cb) * W + wave;
+    if (p >= E) return;
     const int e = topo[topo[TH_IN_EID] + p], s = topo[topo[TH_IN_SRC] + p];
-    if (which == 0) o = f4{li[e * 7 + 2], li[e * 7 + 3], li[e * 7 + 4], li[e * 7 + 5]};
-    else if (which == 1) o = f4{li[e * 7 + 6], yline(s), li[s * 7 + 5], li[s * 7 + 6]};
-    else o = f4{li[s * 7 + 4], 0.f, 0.f, 0.f};
-  } else if (row < 3LL * N + 4LL * E) {
-    const int q = (int)(row - 3LL * N - 3LL * E);
-    const int t = topo[topo[TH_OUT_DST] + q];
-    o = f4{yline(t), li[t * 7 + 5], li[t * 7 + 6], li[t * 7 + 4]};
-  } else {
+    const f4 ea = ld4(li + e * 7 + 2);                              // r, x, b, tau
+    const float she = li[e * 7 + 6];
+    const f4 sa = ld4(li + s * 7 + 2);                              // line NUMBER s: r, x, b, tau
+    const float shs = li[s * 7 + 6];
+    put(3LL * N + 3LL * p, ea);
+    put(3LL * N + 3LL * p + 1, f4{she, yof(sa.x, sa.y), sa.w, shs});
+    put(3LL * N + 3LL * p + 2, f4{sa.z, 0.f, 0.f, 0.f});
+  } else if (c < cb + ci + co) {                                    // ---- four lines in src order: rows 3N + 3E + q
+    const int q0 = ((c - cb - ci) * W + wave) * 4;
+    f4 ta[4];
+    float sh[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int t = topo[topo[TH_OUT_DST] + min(q0 + i, E - 1)];
+      ta[i] = ld4(li + t * 7 + 2);
+      sh[i] = li[t * 7 + 6];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (q0 + i < E) put(3LL * N + 3LL * E + q0 + i, f4{yof(ta[i].x, ta[i].y), ta[i].w, sh[i], ta[i].z});
+  } else {                                                          // ---- per-grid sums (main.py:45,47-51)
+    if (wave != 0) return;
     float sPd = 0.f, sset = 0.f, smin = 0.f, smax = 0.f;
+#pragma unroll 8
     for (int n = 0; n < N; ++n) sPd += bu[n * 6 + 2];
-    for (int q = 0; q < Gn; ++q) { smax += ge[q * 7 + 1]; smin += ge[q * 7 + 2]; sset += ge[q * 7 + 3]; }
-    o = f4{sPd, sset, smin, smax};
+#pragma unroll 4
+    for (int q = 0; q < Gn; ++q) { const f2 pm = ld2(ge + q * 7 + 1); smax += pm.x; smin += pm.y; sset += ge[q * 7 + 3]; }
+    put(3LL * N + 4LL * E, f4{sPd, sset, smin, smax});
   }
-  *row_ptr(out, g * rows + row, lane) = o;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -396,7 +425,9 @@ int gns_launch_pack_params(const float* flat, float* pt, float* pn, const GnsFam
 int gns_launch_pack_inputs(const int* topo, const float* buses, const float* lines, const float* gens, float* out, int N,
                            int E, int Gn, long long Bt, long long groups, hipStream_t st) {
   const long long rows = gns_in_rows(N, E);
-  dim3 grid((unsigned)((rows + 3) / 4), (unsigned)groups);
-  hipLaunchKernelGGL(gns_pack_inputs_kernel, grid, dim3(256), 0, st, topo, buses, lines, gens, out, N, E, Gn, Bt, rows);
+  const int W = 4;
+  const long long chunks = (N + W - 1) / W + (E + W - 1) / W + ((E + 3) / 4 + W - 1) / W + 1, blocks = chunks * ((groups + 7) / 8 * 8);
+  if (blocks > 0x7fffffffLL) return GNS_ESIZE;
+  hipLaunchKernelGGL(gns_pack_inputs_kernel, dim3((unsigned)blocks), dim3(64 * W), 0, st, topo, buses, lines, gens, out, N, E, Gn, Bt, rows, groups);
   return hipGetLastError() == hipSuccess ? GNS_OK : GNS_ELAUNCH;
 }

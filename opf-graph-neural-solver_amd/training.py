@@ -21,7 +21,10 @@ def make_optimizer(model, optimizer_name='Adam', lr=None):
     """``main.py:236-243``: Adagrad with lr 0.01, otherwise Adam with lr 0.001."""
     if optimizer_name == 'Adagrad':
         return torch.optim.Adagrad(model.parameters(), lr=0.01 if lr is None else lr)
-    return torch.optim.Adam(model.parameters(), lr=0.001 if lr is None else lr)
+    # same update rule as the reference's torch.optim.Adam; on the GPU the single-kernel ("fused") implementation replaces
+    # ~10 multi-tensor launches over the 144 parameter tensors
+    on_gpu = all(p.is_cuda for p in model.parameters())
+    return torch.optim.Adam(model.parameters(), lr=0.001 if lr is None else lr, fused=on_gpu)
 
 
 def train_step(model, optimizer, buses, lines, generators, global_batch=None):

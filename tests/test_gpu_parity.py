@@ -53,8 +53,15 @@ def test_single_grid_2d_api_and_cpu_inputs(name):
     assert_close(tot, g['total_loss'][0], REL, what='total')
 
 
+@pytest.fixture(params=['matrix-pipe', 'packed-fma'])
+def dw_engine(request, monkeypatch):
+    """Both weight-gradient engines of the backward kernel (gns_api.hip reads GNS_DW_MFMA on every call)."""
+    monkeypatch.setenv('GNS_DW_MFMA', '1' if request.param == 'matrix-pipe' else '0')
+    return request.param
+
+
 @pytest.mark.parametrize('name', golden_names())
-def test_parameter_gradient_matches_reference_autograd(name):
+def test_parameter_gradient_matches_reference_autograd(name, dw_engine):
     """d(mean total_loss)/d(params) against the reference's own .backward() (GNS/main.py:284-288).
     Gradient tolerance 5e-5 of max|grad| (fp32 products of ~1e5 terms summed in a different order)."""
     g = load_golden(name)
@@ -67,6 +74,24 @@ def test_parameter_gradient_matches_reference_autograd(name):
     for n, p in m.named_parameters():
         if n in none:
             assert float(p.grad.abs().max()) == 0.0, n
+
+
+@pytest.mark.parametrize('case,bt,d,multi,K', [(118, 4099, 20, True, 4), (30, 777, 10, False, 3), (14, 20000, 10, True, 2)])
+def test_weight_gradient_engines_agree_on_large_batches(case, bt, d, multi, K, monkeypatch):
+    """The goldens hold <= 4 grids; here every lane of many waves is live: the matrix-pipe contraction and the
+    packed-FMA register tiles must give the same gradient up to fp32 summation order (1e-6 of max|grad|)."""
+    import opf_graph_neural_solver_amd as amd
+    bu, li, ge = amd.synth.synth_grids(case, bt, seed=5, device='cuda')
+    grads = []
+    for flag in ('1', '0'):
+        monkeypatch.setenv('GNS_DW_MFMA', flag)
+        torch.manual_seed(0)
+        m = amd.GNS(latent_dim=d, hidden_dim=10, K=K, gamma=0.9, multiple_phi=multi).cuda()
+        m(bu, li, ge)[2].mean().backward()
+        grads.append(torch.cat([p.grad.reshape(-1) for p in m.parameters()]).double().cpu())
+    scale = float(grads[1].abs().max())
+    assert scale > 0
+    assert float((grads[0] - grads[1]).abs().max()) <= 1e-6 * scale
 
 
 def test_full_size_batch_against_oracle_sample_and_properties():
