@@ -557,26 +557,44 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
         const f4 a0 = *row_ptr(A.adj, ar, lane);
         float vbar = a0.x, thbar = a0.y;
         const float dpb = a0.z;
-        // The three lists are summed 8 entries at a time with clamped indices, so that 8 independent loads are in
-        // flight; one entry per iteration would pay the full (scalar index -> vector load) latency per entry.
-        const int p0 = in_ptr[n], p1 = in_ptr[n + 1];
-        for (int p = p0; p < p1; p += 4) {
+        // The three lists (lines ending here, lines leaving here, angle-difference incidences) are read with clamped
+        // indices, the first 4 + 4 + 8 entries in ONE round of independent loads (most buses need no second round):
+        // one entry per iteration would pay the full (scalar index -> vector load) latency per entry and per list.
+        const int p0 = in_ptr[n], p1 = in_ptr[n + 1], q0 = out_ptr[n], q1 = out_ptr[n + 1], i0 = incd_ptr[n], i1 = incd_ptr[n + 1];
+        {
+          float ai[4], bi[4], ao[4], bo[4], ci[8];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { const int pp = min(p0 + j, max(p1 - 1, p0)); ai[j] = *slot_ptr(1, min(pp, E - 1)); bi[j] = *slot_ptr(3, min(pp, E - 1)); }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { const int p = q2p[min(min(q0 + j, max(q1 - 1, q0)), E - 1)]; ao[j] = *slot_ptr(0, p); bo[j] = *slot_ptr(2, p); }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int code = incd[min(min(i0 + j, max(i1 - 1, i0)), 4 * E - 1)];
+            const float val = *slot_ptr((code & 2) ? 5 : 4, code >> 2);
+            ci[j] = (code & 1) ? -val : val;
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (p0 + j < p1) { vbar += ai[j]; thbar += bi[j]; }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (q0 + j < q1) { vbar += ao[j]; thbar += bo[j]; }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) if (i0 + j < i1) thbar += ci[j];
+        }
+        for (int p = p0 + 4; p < p1; p += 4) {
           float a[4], b[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) { const int pp = min(p + j, p1 - 1); a[j] = *slot_ptr(1, pp); b[j] = *slot_ptr(3, pp); }
 #pragma unroll
           for (int j = 0; j < 4; ++j) if (p + j < p1) { vbar += a[j]; thbar += b[j]; }
         }
-        const int q0 = out_ptr[n], q1 = out_ptr[n + 1];
-        for (int q = q0; q < q1; q += 4) {
+        for (int q = q0 + 4; q < q1; q += 4) {
           float a[4], b[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) { const int p = q2p[min(q + j, q1 - 1)]; a[j] = *slot_ptr(0, p); b[j] = *slot_ptr(2, p); }
 #pragma unroll
           for (int j = 0; j < 4; ++j) if (q + j < q1) { vbar += a[j]; thbar += b[j]; }
         }
-        const int i0 = incd_ptr[n], i1 = incd_ptr[n + 1];
-        for (int i = i0; i < i1; i += 8) {
+        for (int i = i0 + 8; i < i1; i += 8) {
           float a[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
