@@ -84,7 +84,9 @@ int gns_forward(const gns_config* cfg, const void* topo_dev, const float* params
 /* Reverse pass of the same graph (what total_loss.backward() does at GNS/main.py:288).
  * grad_total / grad_last [Bt] and grad_v / grad_theta [Bt,N] are upstream gradients (any may be NULL = 0).
  * grad_params (flat, state_dict order) is ACCUMULATED into (+=), like autograd does with .grad.
- * L_m.{K-1} (and phi_m.{K-1}) receive exactly zero, matching the reference where they get no gradient. */
+ * L_m.{K-1} (and phi_m.{K-1}) receive exactly zero, matching the reference where they get no gradient.
+ * Environment: GNS_DW_MFMA=0 selects the packed-FMA weight-gradient tiles instead of the (exact fp32) matrix-pipe
+ * contraction; read on every call, results agree to fp32 summation order. */
 int gns_backward(const gns_config* cfg, const void* topo_dev, const float* params, int64_t Bt,
                  const void* fwd_workspace, size_t fwd_workspace_bytes,
                  const float* grad_total, const float* grad_last, const float* grad_v, const float* grad_theta,

@@ -311,12 +311,15 @@ struct LEngine<IN, H, OUT, OUTP, true> {
       if ((lane >> 5) == half) rec_write<IN, H, OUT, OUTP>(rec, lane & 31, x, a1, a2, g1, g2, g3);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      const float* base = rec + (lane >> 4) * R::RS + (lane & 15);
+      // k-slot q = l>>4 of step kk reads row 8(kk>>1) + 2(kk&1) + (q>>1) + 4(q&1): the two 16-lane groups the LDS serves
+      // together are 4 rows apart, and 4 RS = 16 (mod 32 banks) for every record stride (RS = 4 mod 8), so their
+      // 16-column windows never share a bank (rows q, q+1 did: SQ_LDS_BANK_CONFLICT was 32 % of the LDS cycles)
+      const float* base = rec + (((lane >> 5) & 1) + 4 * ((lane >> 4) & 1)) * R::RS + (lane & 15);
       // operands of step kk+1 are read while the matrix pipe works on step kk
       constexpr int NOP = 4 + NB1 + NA4;
       float op[2][NOP];
       auto fetch = [&](float (&o)[NOP], int kk) {
-        const float* b = base + kk * 4 * R::RS;
+        const float* b = base + (8 * (kk >> 1) + 2 * (kk & 1)) * R::RS;
         o[0] = b[R::oG1]; o[1] = b[R::oG2]; o[2] = b[R::oA1]; o[3] = b[R::oA2];
         static_for<0, NB1>([&](auto t_) { constexpr int t = decltype(t_)::value; o[4 + t] = b[R::oX + 16 * t]; });
         static_for<0, NA4>([&](auto t_) { constexpr int t = decltype(t_)::value; o[4 + NB1 + t] = b[R::oG3 + 16 * t]; });
@@ -367,11 +370,11 @@ struct PEngine<IN, H, true> {
     rec_write2<IN, H>(rec, lane, x, a1, g1, g2);                 // all 64 records at once
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const float* base = rec + (lane >> 4) * R::RS + (lane & 15);
+    const float* base = rec + (((lane >> 5) & 1) + 4 * ((lane >> 4) & 1)) * R::RS + (lane & 15);   // row permutation: see LEngine
     constexpr int NOP = 3 + NB1;
     float op[2][NOP];
     auto fetch = [&](float (&o)[NOP], int kk) {
-      const float* b = base + kk * 4 * R::RS;
+      const float* b = base + (8 * (kk >> 1) + 2 * (kk & 1)) * R::RS;
       o[0] = b[R::oG1]; o[1] = b[R::oG2]; o[2] = b[R::oA1];
       static_for<0, NB1>([&](auto t_) { constexpr int t = decltype(t_)::value; o[3 + t] = b[R::oX + 16 * t]; });
     };
