@@ -128,6 +128,10 @@ extern "C" int gns_forward(const gns_config* cfg, const void* topo_dev, const fl
   int waves = GNS_FWD_THREADS / 64;
   if (const char* e = std::getenv("GNS_FWD_WAVES")) { int w = std::atoi(e); if (gns_part_index(w) >= 0 && w * 64 <= GNS_FWD_MAX_THREADS) waves = w; }
   A.part_idx = gns_part_index(waves);
+  {
+    const char* pl = std::getenv("GNS_FWD_PLANE");            // diagnostics: GNS_FWD_PLANE=0 keeps the neighbour gathers on HBM
+    A.plane = ((size_t)N * GNS_LANES * 2 * sizeof(float) <= (size_t)GNS_PLANE_MAX_BYTES && !(pl && pl[0] == '0')) ? 1 : 0;
+  }
   prof_mark(0, true, st);
   rc = gns_launch_forward(d, h, cfg->multiple_phi, A, waves * 64, st);
   prof_mark(0, false, st);

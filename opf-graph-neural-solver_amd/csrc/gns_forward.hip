@@ -191,6 +191,11 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
   const bool live = b < A.Bt;
 
   __shared__ float red[2][GNS_MAXW][GNS_LANES][2];
+  // (v, theta) of every bus of the 64 grids for the step being produced, written by the update phase and gathered by
+  // the line physics (6 neighbour buses per line): 60 KB for case118 instead of ~19 HBM rows per bus and step.
+  extern __shared__ __attribute__((aligned(16))) unsigned char gns_dyn_lds[];
+  f2* plane = reinterpret_cast<f2*>(gns_dyn_lds);
+  const bool use_plane = A.plane != 0;
 
   auto state_row = [&](int slot, int n) { return (((long long)slot * A.G + g) * N + n) * RB; };
 
@@ -254,6 +259,7 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
           for (int q = 0; q < H / 2; ++q) S[j][q] += a2[q];
         });
       }
+      f2 vth_new = f2{s0.x, s0.y};
       static_for<0, NL>([&](auto j_) {
         constexpr int j = decltype(j_)::value;
         constexpr int l = L0 + j;
@@ -273,8 +279,8 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
           f2 y[1];
           mlp_fwd<C::LF_IN, H, 2>(PT + A.t_off[C::NPHI + l] + koff * A.t_sz[C::NPHI + l], x, a1, a2, y);
           float* r0 = reinterpret_cast<float*>(row_ptr(A.state, wr, lane));
-          if constexpr (l == 0) r0[1] = s0.y + y[0].x;                       // theta += L_theta        (main.py:182)
-          else r0[0] = is_gen[n] ? s0.x : s0.x + y[0].x;                     // v += L_v off generators (main.py:184-186)
+          if constexpr (l == 0) { vth_new.y = s0.y + y[0].x; r0[1] = vth_new.y; }                    // theta += L_theta        (main.py:182)
+          else { vth_new.x = is_gen[n] ? s0.x : s0.x + y[0].x; r0[0] = vth_new.x; }                  // v += L_v off generators (main.py:184-186)
         } else {
           f2 upd_m[D / 2], m_new[D / 2];
           mlp_fwd<C::LF_IN, H, D>(PT + A.t_off[C::NPHI + 2] + koff * A.t_sz[C::NPHI + 2], x, a1, a2, upd_m);
@@ -283,6 +289,7 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
           store_pairs<D>(A.state, wr + 1, lane, m_new);
         }
       });
+      if constexpr (grp == 0) { if (use_plane) plane[n * GNS_LANES + lane] = vth_new; }
     };
     for (int u = u0; u < u1; ++u) {
       const int grp = u / N, n = u - grp * N;
@@ -294,10 +301,15 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
     FSTAMP(1)
 
     // ================= phase P: line physics (main.py:34-104), bus-centric, no scatter ================
+    auto vth = [&](int n) {                                           // (v, theta)_{k+1} of any bus of this wave's 64 grids
+      if (use_plane) return plane[n * GNS_LANES + lane];
+      const f4 r = *row_ptr(A.state, state_row(ws, n), lane);
+      return f2{r.x, r.y};
+    };
     float joule = 0.f, v2gs = 0.f;
     for (int n = q0w; n < q1w; ++n) {
       const long long wr = state_row(ws, n);
-      const f4 sn = *row_ptr(A.state, wr, lane);
+      const f2 sn = vth(n);
       const float vn = sn.x, thn = sn.y;
       const f4 b0 = *row_ptr(IN, in_base + 3LL * n, lane);            // Pd,Qd,Gs,Bs
       float sum_pf = 0.f, sum_qf = 0.f, sum_pt = 0.f, sum_qt = 0.f, agg = 0.f;
@@ -305,8 +317,8 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
       for (int p = p0; p < p1; ++p) {                                 // lines with dst == n ("from" messages)
         const int s = in_src[p], ia = in_a[p], ib = in_b[p];
         const f4 e1 = *row_ptr(IN, row_ein + 3LL * p + 1, lane), e2 = *row_ptr(IN, row_ein + 3LL * p + 2, lane);
-        const f4 ss = *row_ptr(A.state, state_row(ws, s), lane);
-        const float tha = row_ptr(A.state, state_row(ws, ia), lane)->y, thb = row_ptr(A.state, state_row(ws, ib), lane)->y;
+        const f2 ss = vth(s);
+        const float tha = vth(ia).y, thb = vth(ib).y;
         const float vs = ss.x, ths = ss.y, vt = vn, tht = thn;
         const float ys = e1.y, taus = e1.z, shs = e1.w, bs = e2.x;
         const float dl = tha - thb;                                   // delta_ij[src]  (bus id used as line index)
@@ -326,8 +338,8 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
       for (int q = q0; q < q1; ++q) {                                 // lines with src == n ("to" messages)
         const int t = out_dst[q], ic = out_c[q], id = out_d[q];
         const f4 o0 = *row_ptr(IN, row_eout + q, lane);               // y_t, tau_t, sh_t, b_t
-        const f4 st = *row_ptr(A.state, state_row(ws, t), lane);
-        const float thc = row_ptr(A.state, state_row(ws, ic), lane)->y, thd = row_ptr(A.state, state_row(ws, id), lane)->y;
+        const f2 st = vth(t);
+        const float thc = vth(ic).y, thd = vth(id).y;
         const float vs = vn, ths = thn, vt = st.x, tht = st.y;
         const float dl = thd - thc;                                   // delta_ji[dst]
         const float angC = tht - ths - dl - o0.z;
@@ -404,7 +416,14 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
 
 template <int D, int H, bool MULTI>
 static int launch_forward_t(const GnsFwdArgs& A, int threads, hipStream_t st) {
-  hipLaunchKernelGGL((gns_forward_kernel<D, H, MULTI>), dim3((unsigned)A.G), dim3(threads), 0, st, A);
+  const size_t dyn = A.plane ? (size_t)A.N * GNS_LANES * sizeof(f2) : 0;
+  static bool attr_set = false;                                      // > 64 KB of dynamic LDS needs the opt-in once per kernel
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gns_forward_kernel<D, H, MULTI>), hipFuncAttributeMaxDynamicSharedMemorySize, GNS_PLANE_MAX_BYTES);
+    (void)hipGetLastError();
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gns_forward_kernel<D, H, MULTI>), dim3((unsigned)A.G), dim3(threads), dyn, st, A);
   return hipGetLastError() == hipSuccess ? GNS_OK : GNS_ELAUNCH;
 }
 

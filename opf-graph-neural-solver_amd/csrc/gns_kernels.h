@@ -8,6 +8,7 @@
 #define GNS_FWD_MAX_THREADS 1024 // register budget of the forward kernel: 128 VGPRs -> 4 waves/SIMD
 #define GNS_BWD_THREADS 512
 #define GNS_MAX_K 64
+#define GNS_PLANE_MAX_BYTES (144 * 1024)   // forward: LDS budget of the (v, theta) plane; larger cases read neighbours from HBM
 
 // (latent_dim, hidden_dim) pairs with compiled kernels
 #define GNS_FOR_EACH_DIMS(X) X(20, 10) X(10, 10)
@@ -37,6 +38,7 @@ struct GnsFwdArgs {
   float gw[GNS_MAX_K];    // gamma^(K-k) rounded to fp32 from a double, like the reference's python float
   long long Bt, G;
   int N, E, K, save, part_idx;
+  int plane;              // 1: the (v, theta) of the step being produced is mirrored in LDS ([N][64] float2, dynamic shared memory)
 };
 
 struct GnsBwdArgs {
