@@ -663,8 +663,10 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
 #pragma unroll
             for (int i = 0; i < D / 2; ++i) x[2 + i] = m[i];
             x[XL - 1] = f2{(float)(p1 - p0), 0.f};
-            f2 a1[H / 2], a2[H / 2], y[OUTP / 2], g3[OUTP / 2], g2[H / 2], g1[H / 2];
-            mlp_fwd<C::LF_IN, H, OUTP>(PT + A.t_off[C::NPHI + l] + koff * A.t_sz[C::NPHI + l], x, a1, a2, y);
+            f2 a1[H / 2], a2[H / 2], g3[OUTP / 2], g2[H / 2], g1[H / 2];
+            // only the hidden activations are needed here: the output layer of L' (a third of L_m's MACs) is not recomputed;
+            // the T-stream of a three-layer block starts with exactly the two-layer layout
+            mlp2_fwd<C::LF_IN, H>(PT + A.t_off[C::NPHI + l] + koff * A.t_sz[C::NPHI + l], x, a1, a2);
             if constexpr (l == 0) g3[0] = f2{a0.y, 0.f};                                  // theta += L_theta (main.py:182)
             else if constexpr (l == 1) g3[0] = f2{is_gen[n] ? 0.f : a0.x, 0.f};           // v moves only without a generator (main.py:184-186)
             else {
