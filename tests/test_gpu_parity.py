@@ -136,6 +136,50 @@ def test_full_size_batch_against_oracle_sample_and_properties():
         assert_close((0.5 * (halves[0] + halves[1])).cpu(), g_all.cpu(), 2e-5, abs_floor=1e-7, what='half-batch mean')
 
 
+@pytest.mark.parametrize('kw', [dict(), dict(latent_dim=10, hidden_dim=10, K=15, gamma=0.9, multiple_phi=True)],
+                         ids=['ctor-defaults-K30-single-phi', 'main.py-run-config-K15-multi-phi'])
+def test_reference_default_configurations_against_oracle(kw):
+    """`GNS()` as the reference constructs it by default (main.py:108: d=10, h=10, K=30, one phi) and as main.py:210-214
+    runs it (K=15, three phis), on case14 / case30 grids.  No golden holds these K (the oracle is pinned by the goldens
+    at K<=10).  With random weights the K=30 recursion amplifies fp32 rounding: the reference's OWN fp32 result is up
+    to 3e-5 from the exact (fp64) one (tools/gpu_depth_conditioning.py), so the 1e-5 bar of the K=4 configs cannot be
+    asked against an fp32 answer.  Checked instead: the HIP result is no further from the fp64 oracle than
+    max(1e-5, 2 x the distance of the reference-order fp32 oracle from it); gradients likewise with 1e-4."""
+    import opf_graph_neural_solver_amd as amd
+    from oracle import gns_oracle as orc
+    torch.manual_seed(3)
+    m = amd.GNS(**kw).cuda()
+    d, K, multi = m.latent_dim, m.K, m.multiple_phis
+    okw = dict(latent_dim=d, K=K, gamma=0.9, multiple_phi=multi)
+
+    def dist(a, b):
+        return float((a.double() - b.double()).abs().max() / b.double().abs().max())
+
+    for case in (14, 30):
+        bu, li, ge = amd.synth.synth_grids(case, 3, seed=11, device='cuda')
+        m.zero_grad()
+        v, th, tot, last = m(bu, li, ge)
+        tot.mean().backward()
+        grad = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).cpu()
+        flat = m.flat_parameters().detach().cpu()
+        g32, g64 = torch.zeros_like(flat), torch.zeros_like(flat, dtype=torch.float64)
+        for b in range(3):
+            f32, f64 = flat.clone().requires_grad_(True), flat.double().requires_grad_(True)
+            o32 = orc.gns_forward(orc.unflatten_params(f32, d, 10, K, multi), bu[b].cpu(), li[b].cpu(), ge[b].cpu(), **okw)
+            o64 = orc.gns_forward(orc.unflatten_params(f64, d, 10, K, multi), bu[b].cpu().double(), li[b].cpu().double(),
+                                  ge[b].cpu().double(), **okw)
+            (o32[2] / 3.0).backward()
+            (o64[2] / 3.0).backward()
+            g32 += f32.grad
+            g64 += f64.grad
+            for name, mine, i in (('v', v[b], 0), ('theta', th[b], 1), ('total', tot[b], 2), ('last', last[b], 3)):
+                ref_noise = dist(o32[i].detach(), o64[i].detach())
+                mine_err = dist(mine.detach().cpu(), o64[i].detach())
+                assert mine_err <= max(REL, 2.0 * ref_noise), f'case{case} {name}[{b}]: {mine_err:.2e} vs fp32 reference noise {ref_noise:.2e}'
+        ref_noise, mine_err = dist(g32, g64), dist(grad, g64)
+        assert mine_err <= max(1e-4, 2.0 * ref_noise), f'case{case} grad: {mine_err:.2e} vs fp32 reference noise {ref_noise:.2e}'
+
+
 def test_ragged_batches_and_upstream_gradients():
     """Batch sizes that do not fill a 64-grid wave (1, 63, 65, 130) and gradients flowing in through v, theta and
     last_loss - checked against autograd on the CPU oracle."""
