@@ -11,6 +11,8 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 typedef const __attribute__((address_space(4))) float* cfp;
 typedef const __attribute__((address_space(4))) int* cip;
 typedef const __attribute__((address_space(4))) f16v* cf16p;
+typedef f16v f16u __attribute__((aligned(4)));                       // a 16-float chunk that starts at any dword
+typedef const __attribute__((address_space(4))) f16u* cf16up;
 
 #define GNS_LEAKY 0.01f   // torch.nn.LeakyReLU default slope (GNS/main.py:23)
 
@@ -39,14 +41,14 @@ __device__ __forceinline__ int opaque_zero() {
 // load is issued: touching one of its registers forces exactly that.
 __device__ __forceinline__ void touch(const f16v& v) { asm volatile("" ::"s"(v[0])); }
 
-template <int NF, class F>
+template <int NF, class VP = cf16p, class F>
 __device__ __forceinline__ void stream_pairs(cfp p, F&& f) {
   // 32-float steps: two s_load_dwordx16 are in flight while the previous 32 floats feed 16 packed FMAs
   constexpr int NST = (NF + 31) / 32;
   p += opaque_zero();
   f16v a0, a1, b0, b1;
-  a0 = *(cf16p)(p);
-  a1 = *(cf16p)(p + 16);
+  a0 = *(VP)(p);
+  a1 = *(VP)(p + 16);
   static_for<0, NST>([&](auto c_) {
     constexpr int c = decltype(c_)::value;
     f16v& c0 = (c & 1) ? b0 : a0;
@@ -56,8 +58,8 @@ __device__ __forceinline__ void stream_pairs(cfp p, F&& f) {
     touch(c0);
     touch(c1);
     if constexpr (c + 1 < NST) {
-      n0 = *(cf16p)(p + 32 * (c + 1));
-      n1 = *(cf16p)(p + 32 * (c + 1) + 16);
+      n0 = *(VP)(p + 32 * (c + 1));
+      n1 = *(VP)(p + 32 * (c + 1) + 16);
     }
     __builtin_amdgcn_sched_barrier(0);
     static_for<0, 16>([&](auto t_) {
@@ -186,6 +188,46 @@ __device__ __forceinline__ void mlp2_fwd(cfp blk, const f2 (&x)[(IN + 1) / 2], f
       constexpr int i = w / H, j = (w % H) / 2;
       const f2 xi = splat(lane_of<i>(x));
       a1[j] = (i == 0) ? s * xi : __builtin_elementwise_fma(s, xi, a1[j]);
+    } else if constexpr (w < B::oW2) {
+      constexpr int j = (w - B::ob1) / 2;
+      a1[j] = lrelu2(a1[j] + s);
+    } else if constexpr (w < B::ob2) {
+      constexpr int q = w - B::oW2, i = q / H, j = (q % H) / 2;
+      const f2 xi = splat(lane_of<i>(a1));
+      a2[j] = (i == 0) ? s * xi : __builtin_elementwise_fma(s, xi, a2[j]);
+    } else {
+      constexpr int j = (w - B::ob2) / 2;
+      a2[j] = lrelu2(a2[j] + s);
+    }
+  });
+  pin_all(a2);
+}
+
+// phi' in two parts.  Every line ending at a bus feeds phi' the SAME latent vector m[dst] (main.py:155), so the first D
+// rows of W1t - 200 of the 370 streamed floats - give the same partial sums u for all of them: phi_head once per bus,
+// phi_tail (the 5 line parameters, b1, layer 2) once per line.  The accumulation order is that of mlp2_fwd
+// (inputs 0..D-1, then D..IN-1, then the bias), so a1, a2 are bitwise the same.
+template <int D, int H>
+__device__ __forceinline__ void phi_head(cfp blk, const f2 (&m)[D / 2], f2 (&u)[H / 2]) {
+  stream_pairs<D * H>(blk, [&](auto w_, f2 s) {
+    constexpr int w = decltype(w_)::value, i = w / H, j = (w % H) / 2;
+    const f2 xi = splat(lane_of<i>(m));
+    u[j] = (i == 0) ? s * xi : __builtin_elementwise_fma(s, xi, u[j]);
+  });
+  pin_all(u);
+}
+template <int IN, int H, int D>
+__device__ __forceinline__ void phi_tail(cfp blk, const f2 (&u)[H / 2], const f2 (&xt)[(IN - D + 1) / 2], f2 (&a1)[H / 2], f2 (&a2)[H / 2]) {
+  using B = TLay2<IN, H>;
+  constexpr int W0 = D * H;
+#pragma unroll
+  for (int j = 0; j < H / 2; ++j) a1[j] = u[j];
+  stream_pairs<B::total - W0, cf16up>(blk + W0, [&](auto w_, f2 s) {
+    constexpr int w = decltype(w_)::value + W0;
+    if constexpr (w < B::ob1) {
+      constexpr int i = w / H, j = (w % H) / 2;
+      const f2 xi = splat(lane_of<i - D>(xt));
+      a1[j] = __builtin_elementwise_fma(s, xi, a1[j]);
     } else if constexpr (w < B::oW2) {
       constexpr int j = (w - B::ob1) / 2;
       a1[j] = lrelu2(a1[j] + s);

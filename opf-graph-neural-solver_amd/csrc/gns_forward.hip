@@ -243,18 +243,27 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
       for (int j = 0; j < NL; ++j)
 #pragma unroll
         for (int q = 0; q < H / 2; ++q) S[j][q] = f2{0.f, 0.f};
-      for (int p = p0; p < p1; ++p) {                       // main.py:155-163 with the output layer of phi folded into L'
-        const f4 e0 = *row_ptr(IN, row_ein + 3LL * p, lane), e1 = *row_ptr(IN, row_ein + 3LL * p + 1, lane);
-        f2 xe[(C::PHI_IN + 1) / 2];
-#pragma unroll
-        for (int i = 0; i < D / 2; ++i) xe[i] = m[i];
-        xe[D / 2] = f2{e0.x, e0.y}; xe[D / 2 + 1] = f2{e0.z, e0.w}; xe[D / 2 + 2] = f2{e1.x, 0.f};
-        static_for<0, (MULTI ? NL : 1)>([&](auto j_) {
+      // main.py:155-163 with the output layer of phi folded into L'.  The latent vector of the destination bus is the
+      // same for every line ending here: its share of phi's first layer is computed once per bus (phi_head)
+      constexpr int NF = MULTI ? NL : 1;
+      f2 uh[NF][H / 2];
+      if (p0 < p1) {
+        static_for<0, NF>([&](auto j_) {
           constexpr int j = decltype(j_)::value;
           constexpr int l = L0 + j;
           constexpr int fphi = MULTI ? (l == 0 ? 1 : (l == 1 ? 0 : 2)) : 0;   // phi_theta, phi_v, phi_m
+          phi_head<D, H>(PT + A.t_off[fphi] + koff * A.t_sz[fphi], m, uh[j]);
+        });
+      }
+      for (int p = p0; p < p1; ++p) {
+        const f4 e0 = *row_ptr(IN, row_ein + 3LL * p, lane), e1 = *row_ptr(IN, row_ein + 3LL * p + 1, lane);
+        const f2 xt[3] = {f2{e0.x, e0.y}, f2{e0.z, e0.w}, f2{e1.x, 0.f}};          // r, x, b, tau, shift
+        static_for<0, NF>([&](auto j_) {
+          constexpr int j = decltype(j_)::value;
+          constexpr int l = L0 + j;
+          constexpr int fphi = MULTI ? (l == 0 ? 1 : (l == 1 ? 0 : 2)) : 0;
           f2 a1[H / 2], a2[H / 2];
-          mlp2_fwd<C::PHI_IN, H>(PT + A.t_off[fphi] + koff * A.t_sz[fphi], xe, a1, a2);
+          phi_tail<C::PHI_IN, H, D>(PT + A.t_off[fphi] + koff * A.t_sz[fphi], uh[j], xt, a1, a2);
 #pragma unroll
           for (int q = 0; q < H / 2; ++q) S[j][q] += a2[q];
         });
