@@ -737,6 +737,7 @@ __global__ void gns_reduce_stage1(const float* __restrict__ slab, float* __restr
   if (i >= sf) return;
   const long long j = blockIdx.y, s0 = nslab * j / GNS_RED_PARTS, s1 = nslab * (j + 1) / GNS_RED_PARTS;
   float acc = 0.f;
+#pragma unroll 8
   for (long long s = s0; s < s1; ++s) acc += slab[s * sf + i];
   part[j * sf + i] = acc;
 }

@@ -149,7 +149,7 @@ static inline void gns_fwd_layout(int N, int E, int d, int h, int K, int multi, 
 
 // ---- backward workspace layout ------------------------------------------------------------------------
 #define GNS_BWD_WAVES 8        // waves per backward workgroup
-#define GNS_RED_PARTS 16       // first-stage partial sums of the slab reduction
+#define GNS_RED_PARTS 64       // first-stage partial sums of the slab reduction
 struct GnsBwdLayout {
   int64_t groups, mq, rows_bus;
   int64_t slab_floats;     // per-wave gradient slab: one float per FOLDED parameter
