@@ -85,6 +85,7 @@ class _GNSFunction(torch.autograd.Function):
         cfg = mod._config(N, lines.shape[1], gens.shape[1])
         dev = buses.device
         need_grad = any(ctx.needs_input_grad[5:])      # grad mode is off inside Function.forward; this is the real signal
+        ctx.set_materialize_grads(False)                # unused outputs (v, theta, last_loss) arrive as None in backward, not as zero-filled tensors
         fwd_b, bwd_b = ctypes.c_size_t(), ctypes.c_size_t()
         _check(lib.gns_workspace_bytes(ctypes.byref(cfg), Bt, int(need_grad), ctypes.byref(fwd_b), ctypes.byref(bwd_b)),
                'gns_workspace_bytes')
