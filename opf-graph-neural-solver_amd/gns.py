@@ -79,12 +79,12 @@ class _Topology:
 
 class _GNSFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mod, topo, buses, lines, gens, *params):
+    def forward(ctx, mod, topo, want_grad, buses, lines, gens, *params):
         lib = load_library()
         Bt, N = buses.shape[0], buses.shape[1]
         cfg = mod._config(N, lines.shape[1], gens.shape[1])
         dev = buses.device
-        need_grad = any(ctx.needs_input_grad[5:])      # grad mode is off inside Function.forward; this is the real signal
+        need_grad = bool(want_grad)                     # evaluation (torch.no_grad()) keeps 2 state slots and saves nothing for a backward
         ctx.set_materialize_grads(False)                # unused outputs (v, theta, last_loss) arrive as None in backward, not as zero-filled tensors
         fwd_b, bwd_b = ctypes.c_size_t(), ctypes.c_size_t()
         _check(lib.gns_workspace_bytes(ctypes.byref(cfg), Bt, int(need_grad), ctypes.byref(fwd_b), ctypes.byref(bwd_b)),
@@ -128,7 +128,7 @@ class _GNSFunction(torch.autograd.Function):
             n = int(np.prod(shp))
             out.append(grad[off:off + n].view(shp))
             off += n
-        return (None, None, None, None, None, *out)
+        return (None, None, None, None, None, None, *out)
 
 
 class GNS(nn.Module):
@@ -270,7 +270,10 @@ class GNS(nn.Module):
         lines = lines.to(dev).contiguous()
         generators = generators.to(dev).contiguous()
         topo = self._topology(lines, generators, buses.shape[1])
-        v, theta, total, last = _GNSFunction.apply(self, topo, buses, lines, generators, *params)
+        # whether a backward pass can follow is decided HERE: inside Function.forward grad mode is always off, and
+        # ctx.needs_input_grad ignores torch.no_grad()
+        want_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        v, theta, total, last = _GNSFunction.apply(self, topo, want_grad, buses, lines, generators, *params)
         if in_dev != dev:
             v, theta, total, last = v.to(in_dev), theta.to(in_dev), total.to(in_dev), last.to(in_dev)
         if single:

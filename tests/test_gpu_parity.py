@@ -180,6 +180,28 @@ def test_reference_default_configurations_against_oracle(kw):
         assert mine_err <= max(1e-4, 2.0 * ref_noise), f'case{case} grad: {mine_err:.2e} vs fp32 reference noise {ref_noise:.2e}'
 
 
+def test_evaluation_mode_saves_nothing_and_matches_training_mode_bitwise():
+    """Under torch.no_grad() (evaluate.py:79) the forward keeps two ping-pong state slots and draws its update units
+    from a queue; in training mode it saves K+1 states for the backward and uses fixed ranges.  Same bits either way,
+    and the evaluation call must not allocate the saved-state workspace."""
+    import opf_graph_neural_solver_amd as amd
+    torch.manual_seed(2)
+    m = amd.GNS(20, 10, 6, 0.9, True).cuda()
+    bu, li, ge = amd.synth.synth_grids(118, 1500, seed=3, device='cuda')
+    torch.cuda.synchronize(); torch.cuda.reset_peak_memory_stats(); base = torch.cuda.memory_allocated()
+    with torch.no_grad():
+        ev = m(bu, li, ge)
+    torch.cuda.synchronize(); peak_eval = torch.cuda.max_memory_allocated() - base
+    assert not ev[2].requires_grad
+    torch.cuda.reset_peak_memory_stats()
+    tr = m(bu, li, ge)
+    torch.cuda.synchronize(); peak_train = torch.cuda.max_memory_allocated() - base
+    assert tr[2].requires_grad
+    for a, b in zip(ev, tr):
+        assert torch.equal(a, b.detach())
+    assert peak_eval < 0.7 * peak_train, (peak_eval, peak_train)
+
+
 def test_ragged_batches_and_upstream_gradients():
     """Batch sizes that do not fill a 64-grid wave (1, 63, 65, 130) and gradients flowing in through v, theta and
     last_loss - checked against autograd on the CPU oracle."""
