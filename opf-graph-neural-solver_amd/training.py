@@ -51,6 +51,24 @@ def fit(model, all_buses, all_lines, all_generators, *, epochs=101, batch_size=1
     optimizer = make_optimizer(model, optimizer_name, lr)
     nr_samples = all_buses.shape[0]
     best, bad, history = float('inf'), 0, []
+    # the id columns of the whole data set are compared once here; the per-call comparison (four device->host syncs per
+    # step) is switched off for the loop: the model then builds / validates the topology on the first batch only
+    if not (bool((all_lines[:, :, 0:2] == all_lines[0, :, 0:2]).all()) and bool((all_generators[:, :, 0] == all_generators[0, :, 0]).all())):
+        raise ValueError('f_bus / t_bus / generator bus columns differ across the data set: train one topology at a time')
+    saved_check = getattr(model, 'topology_check', None)
+    if saved_check is not None:
+        model.topology_check = 'first'
+        model._topo_cache.clear()          # a cached topology of the same shape from an earlier data set must not be reused unchecked
+    try:
+        return _fit_loop(model, optimizer, all_buses, all_lines, all_generators, nr_samples, epochs, batch_size, optimizer_name,
+                         case_nr, print_every, checkpoint_dir, log, best, bad, history)
+    finally:
+        if saved_check is not None:
+            model.topology_check = saved_check
+
+
+def _fit_loop(model, optimizer, all_buses, all_lines, all_generators, nr_samples, epochs, batch_size, optimizer_name, case_nr,
+              print_every, checkpoint_dir, log, best, bad, history):
     for epoch in range(epochs):
         finals = []
         for lo in range(0, nr_samples - batch_size + 1, batch_size):
