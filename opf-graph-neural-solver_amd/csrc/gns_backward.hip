@@ -7,8 +7,9 @@
 //   Pb-edge per line: adjoints of the line physics w.r.t. v, theta of its 2 (+4 bus-id-as-line-index) buses,
 //           stored per line (no atomics); every bus later gathers its own lists in a fixed order
 //   Ub      per bus: gather, then the update step is recomputed and back-propagated; the weight gradient
-//           (a contraction over the 64 grids of the wave) goes through an LDS transpose into a
-//           weight-stationary 4x4 register tile per lane and is accumulated into a per-wave slab.
+//           (a contraction over the 64 grids of the wave) goes through an LDS transpose into register-resident
+//           accumulators - fp32 MFMA tiles by default, 4x4 packed-FMA tiles with GNS_DW_MFMA=0 - that are
+//           flushed once per (family, step) into a per-wave slab.
 // delta_q carries no gradient: it is qg_new - Qd + Bs v^2 + (the very sums qg_new was built from), i.e.
 // identically zero as a function of (v, theta) (main.py:64-76 vs :83,98-103).
 #include "gns_device.h"
