@@ -202,6 +202,30 @@ def test_evaluation_mode_saves_nothing_and_matches_training_mode_bitwise():
     assert peak_eval < 0.7 * peak_train, (peak_eval, peak_train)
 
 
+def test_reference_style_per_grid_training_loop_equals_the_batched_step():
+    """main.py:277-291 as written: one model call per grid (2-D CPU tensors, keyword arguments), the losses collected in
+    a Python list, `torch.mean(torch.stack(losses)).backward()`.  The gradients must equal those of ONE batched call."""
+    import opf_graph_neural_solver_amd as amd
+    B, L, G = amd.get_BLG()
+    torch.manual_seed(4)
+    m = amd.GNS(latent_dim=20, hidden_dim=10, K=4, gamma=0.9, multiple_phi=True).cuda()
+    bu, li, ge = amd.synth.synth_grids(14, 6, seed=9)            # CPU tensors, like utils.load_all_grids returns
+    losses, last_losses = [], []
+    for i in range(6):
+        v, theta, loss, last_loss = m(buses=bu[i], lines=li[i], generators=ge[i], B=B, L=L, G=G)
+        assert loss.requires_grad and loss.dim() == 0
+        losses.append(loss)
+        last_losses.append(last_loss)
+    torch.mean(torch.stack(losses)).backward()
+    g_loop = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
+    m.zero_grad()
+    _, _, tot, _ = m(bu.cuda(), li.cuda(), ge.cuda(), B, L, G)
+    tot.mean().backward()
+    g_batch = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+    assert_close(torch.stack(losses).detach().cpu(), tot.detach().cpu(), 1e-6, what='per-grid losses')
+    assert_close(g_loop.cpu(), g_batch.cpu(), 2e-5, abs_floor=1e-7, what='loop vs batched gradient')
+
+
 def test_ragged_batches_and_upstream_gradients():
     """Batch sizes that do not fill a 64-grid wave (1, 63, 65, 130) and gradients flowing in through v, theta and
     last_loss - checked against autograd on the CPU oracle."""
