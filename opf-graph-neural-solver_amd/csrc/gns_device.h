@@ -295,6 +295,16 @@ __device__ __forceinline__ void load_pairs(const float* base, long long row, int
     if constexpr (2 * q + 1 < D / 2) m[2 * q + 1] = f2{t.z, t.w};
   });
 }
+// streaming variant: rows written once for a later kernel (the backward) and never re-read by this one
+template <int D>
+__device__ __forceinline__ void store_pairs_nt(float* base, long long row, int lane, const f2 (&m)[D / 2]) {
+  static_for<0, (D + 3) / 4>([&](auto q_) {
+    constexpr int q = decltype(q_)::value;
+    f4 t = {m[2 * q].x, m[2 * q].y, 0.f, 0.f};
+    if constexpr (2 * q + 1 < D / 2) { t.z = m[2 * q + 1].x; t.w = m[2 * q + 1].y; }
+    __builtin_nontemporal_store(t, row_ptr(base, row + q, lane));
+  });
+}
 template <int D>
 __device__ __forceinline__ void store_pairs(float* base, long long row, int lane, const f2 (&m)[D / 2]) {
   static_for<0, (D + 3) / 4>([&](auto q_) {

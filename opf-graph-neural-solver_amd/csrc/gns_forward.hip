@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
         constexpr int fphi = MULTI ? (l == 0 ? 1 : (l == 1 ? 0 : 2)) : 0;
         constexpr int js = MULTI ? j : 0;                   // the single phi: one sum serves all three L nets (main.py:169-171)
         if (A.save && (MULTI || l == 0))
-          store_pairs<H>(A.msg, ((((long long)k * A.G + g) * N + n) * C::NPHI + fphi) * C::HQ, lane, S[js]);
+          store_pairs_nt<H>(A.msg, ((((long long)k * A.G + g) * N + n) * C::NPHI + fphi) * C::HQ, lane, S[js]);
         f2 x[(C::LF_IN + 1) / 2];                           // [v theta | dp dq | m | sum h | deg]
         x[0] = f2{s0.x, s0.y}; x[1] = f2{s0.z, s0.w};
 #pragma unroll
