@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
           mlp_fwd<C::LF_IN, H, D>(PT + A.t_off[C::NPHI + 2] + koff * A.t_sz[C::NPHI + 2], x, a1, a2, upd_m);
 #pragma unroll
           for (int i = 0; i < D / 2; ++i) m_new[i] = m[i] + upd_m[i];        // main.py:188
-          store_pairs<D>(A.state, wr + 1, lane, m_new);
+          store_pairs_nt<D>(A.state, wr + 1, lane, m_new);
         }
       });
       if constexpr (grp == 0) { if (use_plane) plane[n * GNS_LANES + lane] = vth_new; }
