@@ -507,22 +507,25 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
       const float pgbar = lbar / (low1 ? 2.f * (gsum.y - gsum.z) : 2.f * (gsum.w - gsum.y));   // d lambda / d p_global (main.py:47-51)
 
       // ---------------- Pb-edge ----------------
-#ifdef GNS_ABLATE_PHYS
-      for (int p = e0; p < e0; ++p) {
-#else
-      for (int p = e0; p < e1; ++p) {
-#endif
+      // Two lines per iteration: the 24 loads of both are issued before either is used (the phase waits on loads, not
+      // on the VALU, and a wave has only one partner on its SIMD to hide them).
+      struct EdgeIn { f4 e1v, o0, ss, st; float tha, thb, thc, thd, Fb, Tb; };
+      auto edge_load = [&](int p, EdgeIn& L) {
         const int s = in_src[p], t = in_dst[p], ia = in_a[p], ib = in_b[p], q = p2q[p], ic = out_c[q], id = out_d[q];
-        const f4 e1v = *row_ptr(IN, row_ein + 3LL * p + 1, lane);           // shift_e, y_s, tau_s, sh_s
-        const f4 o0 = *row_ptr(IN, row_eout + q, lane);                      // y_t, tau_t, sh_t, b_t
-        const f4 ss = *row_ptr(A.state, state_row(k + 1, s), lane), st = *row_ptr(A.state, state_row(k + 1, t), lane);
-        const float tha = row_ptr(A.state, state_row(k + 1, ia), lane)->y, thb = row_ptr(A.state, state_row(k + 1, ib), lane)->y;
-        const float thc = row_ptr(A.state, state_row(k + 1, ic), lane)->y, thd = row_ptr(A.state, state_row(k + 1, id), lane)->y;
-        const float Fb = row_ptr(A.adj, adj_row(t), lane)->z;                // dp[t] += p_from   (main.py:94)
-        const float Tb = row_ptr(A.adj, adj_row(s), lane)->z;                // dp[s] += p_to     (main.py:95)
-        const float vs = ss.x, ths = ss.y, vt = st.x, tht = st.y;
+        L.e1v = *row_ptr(IN, row_ein + 3LL * p + 1, lane);                  // shift_e, y_s, tau_s, sh_s
+        L.o0 = *row_ptr(IN, row_eout + q, lane);                             // y_t, tau_t, sh_t, b_t
+        L.ss = *row_ptr(A.state, state_row(k + 1, s), lane); L.st = *row_ptr(A.state, state_row(k + 1, t), lane);
+        L.tha = row_ptr(A.state, state_row(k + 1, ia), lane)->y; L.thb = row_ptr(A.state, state_row(k + 1, ib), lane)->y;
+        L.thc = row_ptr(A.state, state_row(k + 1, ic), lane)->y; L.thd = row_ptr(A.state, state_row(k + 1, id), lane)->y;
+        L.Fb = row_ptr(A.adj, adj_row(t), lane)->z;                          // dp[t] += p_from   (main.py:94)
+        L.Tb = row_ptr(A.adj, adj_row(s), lane)->z;                          // dp[s] += p_to     (main.py:95)
+      };
+      auto edge_adjoint = [&](int p, const EdgeIn& L) {
+        const f4 e1v = L.e1v, o0 = L.o0;
+        const float Fb = L.Fb, Tb = L.Tb;
+        const float vs = L.ss.x, ths = L.ss.y, vt = L.st.x, tht = L.st.y;
         const float ys = e1v.y, taus = e1v.z, shs = e1v.w;
-        const float dl = tha - thb, dl2 = thd - thc;
+        const float dl = L.tha - L.thb, dl2 = L.thd - L.thc;
         float sA, cA, sB, cB, sD, cD, sC, cC, sD2, cD2;
         sincosf(ths - tht - dl - shs, &sA, &cA);
         sincosf(tht - ths - dl + shs, &sB, &cB);
@@ -550,6 +553,17 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
         dtht += Cb; dths -= Cb;
         *slot_ptr(0, p) = dvs; *slot_ptr(1, p) = dvt; *slot_ptr(2, p) = dths; *slot_ptr(3, p) = dtht;
         *slot_ptr(4, p) = dbar; *slot_ptr(5, p) = dbar2;
+      };
+#ifdef GNS_ABLATE_PHYS
+      for (int p = e0; p < e0; p += 2) {
+#else
+      for (int p = e0; p < e1; p += 2) {
+#endif
+        EdgeIn L0, L1;
+        edge_load(p, L0);
+        edge_load(min(p + 1, e1 - 1), L1);
+        edge_adjoint(p, L0);
+        if (p + 1 < e1) edge_adjoint(p + 1, L1);
       }
       STAMP(2)
       __syncthreads();
