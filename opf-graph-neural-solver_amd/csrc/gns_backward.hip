@@ -482,20 +482,33 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
 
       // ---------------- Pb-0 (also closes step k+1: identity paths + the input adjoints its sweeps collected) --------
       float lb = 0.f;
-      for (int n = n0; n < n1; ++n) {
-        const long long ar = adj_row(n);
-        const f4 s1 = *row_ptr(A.state, state_row(k + 1, n), lane);
-        f4 a0 = *row_ptr(A.adj, ar, lane);
-        if (k < K - 1) {
-          const f4 xsum = *row_ptr(A.adj, ar + 1, lane);
-          a0 = f4{a0.x + xsum.x, a0.y + xsum.y, xsum.z, 0.f};               // main.py:182,186 identity paths
+      for (int nb = n0; nb < n1; nb += 4) {                                  // four buses per round: 16 independent row loads in flight
+        f4 s1[4], a0[4], xs[4], b1[4];
 #pragma unroll
-          for (int q = 0; q < 1 + RHB; ++q) *row_ptr(A.adj, ar + 1 + q, lane) = f4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) {
+          const int n = min(nb + j, n1 - 1);
+          const long long ar = adj_row(n);
+          s1[j] = *row_ptr(A.state, state_row(k + 1, n), lane);
+          a0[j] = *row_ptr(A.adj, ar, lane);
+          xs[j] = *row_ptr(A.adj, ar + 1, lane);
+          b1[j] = *row_ptr(IN, in_base + 3LL * n + 1, lane);                // Pmin,Pset,Pmax per bus
         }
-        a0.z = a0.z + cdp * s1.z;
-        *row_ptr(A.adj, ar, lane) = a0;
-        const f4 b1 = *row_ptr(IN, in_base + 3LL * n + 1, lane);            // Pmin,Pset,Pmax per bus
-        lb += a0.z * (low2 ? 2.f * (b1.y - b1.x) : 2.f * (b1.z - b1.y));    // d Pg_new / d lambda  (main.py:53-57)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = nb + j;
+          if (n < n1) {
+            const long long ar = adj_row(n);
+            f4 a = a0[j];
+            if (k < K - 1) {
+              a = f4{a.x + xs[j].x, a.y + xs[j].y, xs[j].z, 0.f};           // main.py:182,186 identity paths
+#pragma unroll
+              for (int q = 0; q < 1 + RHB; ++q) *row_ptr(A.adj, ar + 1 + q, lane) = f4{0.f, 0.f, 0.f, 0.f};
+            }
+            a.z = a.z + cdp * s1[j].z;
+            *row_ptr(A.adj, ar, lane) = a;
+            lb += a.z * (low2 ? 2.f * (b1[j].y - b1[j].x) : 2.f * (b1[j].z - b1[j].y));    // d Pg_new / d lambda  (main.py:53-57)
+          }
+        }
       }
       STAMP(0)
       red[k & 1][wave][lane] = lb;
