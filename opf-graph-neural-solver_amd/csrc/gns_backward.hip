@@ -586,6 +586,8 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
       for (int n = n0; n < n1; ++n) {
         const long long ar = adj_row(n);
         const f4 a0 = *row_ptr(A.adj, ar, lane);
+        const f4 s1 = *row_ptr(A.state, state_row(k + 1, n), lane);         // issued with the list loads below, used after them
+        const float Gs = row_ptr(IN, in_base + 3LL * n, lane)->z;
         float vbar = a0.x, thbar = a0.y;
         const float dpb = a0.z;
         // The three lists (lines ending here, lines leaving here, angle-difference incidences) are read with clamped
@@ -636,8 +638,6 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
 #pragma unroll
           for (int j = 0; j < 8; ++j) if (i + j < i1) thbar += a[j];
         }
-        const f4 s1 = *row_ptr(A.state, state_row(k + 1, n), lane);
-        const float Gs = row_ptr(IN, in_base + 3LL * n, lane)->z;
         vbar += (pgbar - dpb) * (2.f * Gs * s1.x);     // -Gs v^2 in dp (main.py:82) and +Gs v^2 in p_global (main.py:45)
         *row_ptr(A.adj, ar, lane) = f4{vbar, thbar, dpb, 0.f};
       }
