@@ -401,14 +401,24 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
     if (A.save && wave == 0)
       reinterpret_cast<f2*>(A.lam)[((long long)k * A.G + g) * GNS_LANES + lane] = f2{lam, (low1 ? 1.f : 0.f) + (low2 ? 2.f : 0.f)};
     float sq = 0.f;
-    for (int n = q0w; n < q1w; ++n) {
-      const long long wr = state_row(ws, n);
-      const f4 b1 = *row_ptr(IN, in_base + 3LL * n + 1, lane);         // Pmin,Pset,Pmax,v0 summed per bus
-      f4 sn = *row_ptr(A.state, wr, lane);
-      const float pg = low2 ? b1.x + 2.f * (b1.y - b1.x) * lam : 2.f * b1.y - b1.z + 2.f * (b1.z - b1.y) * lam;   // main.py:53-57
-      sn.z = pg + sn.z;                                               // main.py:81-82,96
-      *row_ptr(A.state, wr, lane) = sn;
-      sq += sn.z * sn.z + sn.w * sn.w;
+    for (int nb = q0w; nb < q1w; nb += 4) {                           // four buses per round: their 8 row loads fly together
+      f4 b1[4], sn[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = min(nb + j, q1w - 1);
+        b1[j] = *row_ptr(IN, in_base + 3LL * n + 1, lane);            // Pmin,Pset,Pmax,v0 summed per bus
+        sn[j] = *row_ptr(A.state, state_row(ws, n), lane);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (nb + j < q1w) {
+          const float pg = low2 ? b1[j].x + 2.f * (b1[j].y - b1[j].x) * lam
+                                : 2.f * b1[j].y - b1[j].z + 2.f * (b1[j].z - b1[j].y) * lam;      // main.py:53-57
+          sn[j].z = pg + sn[j].z;                                     // main.py:81-82,96
+          *row_ptr(A.state, state_row(ws, nb + j), lane) = sn[j];
+          sq += sn[j].z * sn[j].z + sn[j].w * sn[j].w;
+        }
+      }
     }
     tot_part += A.gw[k] * (sq * invN);           // main.py:198
     last_part = sq * invN;                                            // main.py:199
