@@ -101,6 +101,19 @@ int gns_backward(const gns_config* cfg, const void* topo_dev, const float* param
 int gns_profile_enable(int capacity);
 int gns_profile_read(int backward, float* ms_sum, int* launches);
 
+/* ---- configuration (process-wide; set before launching, not concurrently with launches) ------------
+ * The library reads its environment ONCE, at the first call of any entry point below or of gns_forward /
+ * gns_backward (GNS_FWD_MAPPING=lane|lds, GNS_GW_PACK, GNS_FWD_WAVES, GNS_FWD_PLANE, GNS_DW_MFMA); these
+ * setters override those defaults explicitly.  Options:
+ *   "fwd_mapping" 0 auto | 1 lane-per-grid kernels (state streamed through HBM) | 2 grid-per-workgroup kernels (state on chip)
+ *   "gw_pack"     grids per workgroup of the grid-per-workgroup mapping (0 = auto)
+ *   "fwd_waves"   waves per workgroup of the lane-per-grid forward (1,2,4,8,16)
+ *   "fwd_plane"   0: the lane-per-grid forward gathers neighbour (v, theta) from HBM instead of LDS
+ *   "dw_mfma"     0: weight-gradient contraction on packed FMAs instead of the fp32 matrix pipe
+ * Both mappings and both engines compute the same function of the reference (GNS/main.py:140-202, :288). */
+int gns_set_option(const char* name, int value);
+int gns_get_option(const char* name, int* value);
+
 #ifdef __cplusplus
 }
 #endif

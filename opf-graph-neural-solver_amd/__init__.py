@@ -13,6 +13,6 @@ from . import synth
 from . import dist
 from . import prepare, metrics, training
 from .prepare import prepare_grids
-from ._lib import load_library, library_path
+from ._lib import load_library, library_path, set_option, get_option
 
-__all__ = ['GNS', 'LearningBlock', 'get_BLG', 'GNSError', 'synth', 'dist', 'prepare', 'metrics', 'training', 'prepare_grids', 'load_library', 'library_path']
+__all__ = ['GNS', 'LearningBlock', 'get_BLG', 'GNSError', 'synth', 'dist', 'prepare', 'metrics', 'training', 'prepare_grids', 'load_library', 'library_path', 'set_option', 'get_option']

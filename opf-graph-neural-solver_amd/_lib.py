@@ -53,12 +53,31 @@ def load_library():
     lib.gns_backward.argtypes = [cfgp, vp, vp, i64, vp, sz, vp, vp, vp, vp, vp, vp, sz, vp]
     lib.gns_profile_enable.argtypes = [ctypes.c_int]
     lib.gns_profile_read.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]
+    lib.gns_set_option.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    lib.gns_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
     for f in ('gns_profile_enable', 'gns_profile_read', 'gns_param_count', 'gns_config_supported', 'gns_topology_bytes', 'gns_prepare_topology',
-              'gns_workspace_bytes', 'gns_forward', 'gns_backward', 'gns_profile_enable', 'gns_profile_read'):
+              'gns_workspace_bytes', 'gns_forward', 'gns_backward', 'gns_profile_enable', 'gns_profile_read',
+              'gns_set_option', 'gns_get_option'):
         getattr(lib, f).restype = ctypes.c_int
     _LIB = lib
     return lib
 
 
 EXPORTS = ('gns_version', 'gns_param_count', 'gns_config_supported', 'gns_topology_bytes', 'gns_prepare_topology',
-           'gns_workspace_bytes', 'gns_forward', 'gns_backward', 'gns_profile_enable', 'gns_profile_read')
+           'gns_workspace_bytes', 'gns_forward', 'gns_backward', 'gns_profile_enable', 'gns_profile_read',
+           'gns_set_option', 'gns_get_option')
+
+
+def set_option(name: str, value: int) -> None:
+    """Process-wide tuning knob of the library (include/gns_hip.h, "configuration")."""
+    rc = load_library().gns_set_option(name.encode(), int(value))
+    if rc != 0:
+        raise ValueError(f'gns_set_option({name!r}, {value}) rejected: {GNS_ERRORS.get(rc, rc)}')
+
+
+def get_option(name: str) -> int:
+    v = ctypes.c_int()
+    rc = load_library().gns_get_option(name.encode(), ctypes.byref(v))
+    if rc != 0:
+        raise ValueError(f'unknown option {name!r}')
+    return v.value

@@ -4,6 +4,56 @@
 #include <cstring>
 #include <cstdlib>
 #include "gns_kernels.h"
+#include "gns_gridwg.h"
+
+// ---- process-wide tuning knobs: read from the environment ONCE (first call), never per launch ----------------------
+namespace {
+struct GnsTuning {
+  int fwd_mapping;   // GNS_FWD_MAPPING: 0 auto, 1 "lane" (lane = grid, state streamed through HBM), 2 "lds" (grid per workgroup, state on chip)
+  int gw_pack;       // GNS_GW_PACK: grids per workgroup of the lds mapping (0 = auto)
+  int fwd_waves;     // GNS_FWD_WAVES: waves per workgroup of the lane mapping
+  int fwd_plane;     // GNS_FWD_PLANE=0: lane mapping gathers neighbour (v, theta) from HBM instead of the LDS plane
+  int dw_mfma;       // GNS_DW_MFMA=0: packed-FMA weight-gradient engine instead of the matrix pipe
+  int gw_ready;      // gns_gw_init_device() succeeded
+};
+GnsTuning make_tuning() {
+  GnsTuning t{0, 0, GNS_FWD_THREADS / 64, 1, 1, 0};
+  if (const char* e = std::getenv("GNS_FWD_MAPPING")) t.fwd_mapping = !std::strcmp(e, "lane") ? 1 : (!std::strcmp(e, "lds") ? 2 : 0);
+  if (const char* e = std::getenv("GNS_GW_PACK")) { const int p = std::atoi(e); if (p >= 1 && p <= 16) t.gw_pack = p; }
+  if (const char* e = std::getenv("GNS_FWD_WAVES")) { const int w = std::atoi(e); if (gns_part_index(w) >= 0 && w * 64 <= GNS_FWD_MAX_THREADS) t.fwd_waves = w; }
+  if (const char* e = std::getenv("GNS_FWD_PLANE")) t.fwd_plane = e[0] == '0' ? 0 : 1;
+  if (const char* e = std::getenv("GNS_DW_MFMA")) t.dw_mfma = e[0] == '0' ? 0 : 1;
+  t.gw_ready = gns_gw_init_device() == GNS_OK ? 1 : 0;
+  return t;
+}
+GnsTuning& tuning() {
+  static GnsTuning t = make_tuning();            // C++11: thread-safe one-time initialisation
+  return t;
+}
+}  // namespace
+
+// Explicit configuration (include/gns_hip.h).  The environment variables of the same meaning only seed the defaults.
+extern "C" int gns_set_option(const char* name, int value) {
+  if (!name) return GNS_EINVAL;
+  GnsTuning& t = tuning();
+  if (!std::strcmp(name, "fwd_mapping")) { if (value < 0 || value > 2) return GNS_EINVAL; t.fwd_mapping = value; return GNS_OK; }
+  if (!std::strcmp(name, "gw_pack")) { if (value < 0 || value > 16) return GNS_EINVAL; t.gw_pack = value; return GNS_OK; }
+  if (!std::strcmp(name, "fwd_waves")) { if (gns_part_index(value) < 0 || value * 64 > GNS_FWD_MAX_THREADS) return GNS_EINVAL; t.fwd_waves = value; return GNS_OK; }
+  if (!std::strcmp(name, "fwd_plane")) { t.fwd_plane = value ? 1 : 0; return GNS_OK; }
+  if (!std::strcmp(name, "dw_mfma")) { t.dw_mfma = value ? 1 : 0; return GNS_OK; }
+  return GNS_EINVAL;
+}
+extern "C" int gns_get_option(const char* name, int* value) {
+  if (!name || !value) return GNS_EINVAL;
+  const GnsTuning& t = tuning();
+  if (!std::strcmp(name, "fwd_mapping")) *value = t.fwd_mapping;
+  else if (!std::strcmp(name, "gw_pack")) *value = t.gw_pack;
+  else if (!std::strcmp(name, "fwd_waves")) *value = t.fwd_waves;
+  else if (!std::strcmp(name, "fwd_plane")) *value = t.fwd_plane;
+  else if (!std::strcmp(name, "dw_mfma")) *value = t.dw_mfma;
+  else return GNS_EINVAL;
+  return GNS_OK;
+}
 
 static bool dims_supported(int d, int h) {
 #define GNS_CASE(DD, HH) if (d == DD && h == HH) return true;
@@ -113,8 +163,28 @@ extern "C" int gns_forward(const gns_config* cfg, const void* topo_dev, const fl
   float* pt = (float*)(ws + L.off_pt);
   float* pn = (float*)(ws + L.off_pn);
   float* pin = (float*)(ws + L.off_in);
+  const GnsTuning& T = tuning();
   rc = gns_launch_pack_params(params, pt, pn, fam, K, d, h, st);
   if (rc != GNS_OK) return rc;
+  // Evaluation (nothing saved for a backward): the grid-per-workgroup mapping keeps the whole state on chip.
+  {
+    int P = T.gw_pack > 0 ? T.gw_pack : 1;
+    const bool can = !save_state && T.gw_ready && gns_gw_supported(N, E, d, h, cfg->multiple_phi, P);
+    const bool want = T.fwd_mapping == 2 || (T.fwd_mapping == 0 && N >= 48);
+    if (can && want) {
+      GnsGwFwdArgs G;
+      std::memset(&G, 0, sizeof(G));
+      G.topo = (const int*)topo_dev; G.pt = pt; G.buses = buses; G.lines = lines; G.gens = generators;
+      G.v_out = v; G.theta_out = theta; G.total_out = total_loss; G.last_out = last_loss;
+      for (int i = 0; i < fam.nfam; ++i) { G.t_off[i] = fam.t_off[i]; G.t_sz[i] = fam.t_sz[i]; }
+      for (int k = 0; k < K; ++k) G.gw[k] = (float)std::pow((double)cfg->gamma, (double)(K - k));   // main.py:198
+      G.Bt = Bt; G.N = N; G.E = E; G.Gn = Gn; G.K = K; G.save = 0; G.P = P; G.WPG = ((N > E ? N : E) + 63) / 64;
+      prof_mark(0, true, st);
+      rc = gns_gw_launch_forward(d, h, cfg->multiple_phi, G, st);
+      prof_mark(0, false, st);
+      return rc;
+    }
+  }
   rc = gns_launch_pack_inputs((const int*)topo_dev, buses, lines, generators, pin, N, E, Gn, Bt, L.groups, st);
   if (rc != GNS_OK) return rc;
   GnsFwdArgs A;
@@ -125,13 +195,9 @@ extern "C" int gns_forward(const gns_config* cfg, const void* topo_dev, const fl
   for (int i = 0; i < fam.nfam; ++i) { A.t_off[i] = fam.t_off[i]; A.t_sz[i] = fam.t_sz[i]; }
   for (int k = 0; k < K; ++k) A.gw[k] = (float)std::pow((double)cfg->gamma, (double)(K - k));   // main.py:198
   A.Bt = Bt; A.G = L.groups; A.N = N; A.E = E; A.K = K; A.save = save_state ? 1 : 0;
-  int waves = GNS_FWD_THREADS / 64;
-  if (const char* e = std::getenv("GNS_FWD_WAVES")) { int w = std::atoi(e); if (gns_part_index(w) >= 0 && w * 64 <= GNS_FWD_MAX_THREADS) waves = w; }
+  const int waves = T.fwd_waves;
   A.part_idx = gns_part_index(waves);
-  {
-    const char* pl = std::getenv("GNS_FWD_PLANE");            // diagnostics: GNS_FWD_PLANE=0 keeps the neighbour gathers on HBM
-    A.plane = ((size_t)N * GNS_LANES * 2 * sizeof(float) <= (size_t)GNS_PLANE_MAX_BYTES && !(pl && pl[0] == '0')) ? 1 : 0;
-  }
+  A.plane = ((size_t)N * GNS_LANES * 2 * sizeof(float) <= (size_t)GNS_PLANE_MAX_BYTES && T.fwd_plane) ? 1 : 0;
   prof_mark(0, true, st);
   rc = gns_launch_forward(d, h, cfg->multiple_phi, A, waves * 64, st);
   prof_mark(0, false, st);
@@ -176,8 +242,7 @@ extern "C" int gns_backward(const gns_config* cfg, const void* topo_dev, const f
   prof_mark(1, true, st);
   // The weight-gradient contraction over the grids runs on the matrix pipe (exact fp32) unless GNS_DW_MFMA=0 asks for
   // the packed-FMA register tiles; both are parity-tested (gns_backward.hip, "weight-gradient engines").
-  const char* mf = std::getenv("GNS_DW_MFMA");
-  rc = gns_launch_backward(d, h, cfg->multiple_phi, (mf && mf[0] == '0') ? 0 : 1, A, blocks, st);
+  rc = gns_launch_backward(d, h, cfg->multiple_phi, tuning().dw_mfma, A, blocks, st);
   prof_mark(1, false, st);
   if (rc != GNS_OK) return rc;
   return gns_launch_reduce(A.slab, (float*)(bw + B.off_part), (float*)(bw + B.off_tmp), params, grad_params, nslab, B.slab_floats,

@@ -46,6 +46,8 @@ enum {
   TH_IN_DST,    // [E]   t = dst[e] of in-edge p
   TH_UPART,     // [GNS_NPART][GNS_MAXW+1] forward update phase: ranges of units u = grp*N + n (grp 0: theta+v, 1: m), balanced by work
   TH_PPART,     // [GNS_NPART][GNS_MAXW+1] forward physics phase: bus ranges balanced by incident lines
+  TH_LANE_BUS,  // [N]   grid-per-workgroup mapping: bus handled by bus lane i (buses in descending in-degree order, so the
+                //       lanes of one wave run similar trip counts in their incidence loops)
   TH_TOTAL,     // blob length in words
   TH_HDR_WORDS = 32
 };

@@ -121,6 +121,16 @@ int build(int N, int E, int Gn, const int32_t* src, const int32_t* dst, const in
   b.put(TH_PART, part); b.put(TH_P2Q, p2q); b.put(TH_Q2P, q2p); b.put(TH_EPART, epart);
   b.put(TH_INCD_PTR, incd_ptr); b.put(TH_INCD, incd); b.put(TH_IN_DST, in_dst);
   b.put(TH_UPART, upart); b.put(TH_PPART, ppart);
+  {
+    std::vector<int32_t> lane_bus(N);
+    std::iota(lane_bus.begin(), lane_bus.end(), 0);
+    std::stable_sort(lane_bus.begin(), lane_bus.end(), [&](int32_t a, int32_t c) {
+      const int da = in_ptr[a + 1] - in_ptr[a], dc = in_ptr[c + 1] - in_ptr[c];
+      if (da != dc) return da > dc;
+      return (out_ptr[a + 1] - out_ptr[a]) > (out_ptr[c + 1] - out_ptr[c]);
+    });
+    b.put(TH_LANE_BUS, lane_bus);
+  }
   b.w[TH_TOTAL] = (int32_t)b.w.size();
   out.swap(b.w);
   return GNS_OK;
@@ -128,7 +138,7 @@ int build(int N, int E, int Gn, const int32_t* src, const int32_t* dst, const in
 
 size_t blob_words(int N, int E, int Gn) {
   return TH_HDR_WORDS + 2 * (size_t)(N + 1) + 12 * (size_t)E + (size_t)N + (size_t)(N + 1) + (size_t)std::max(Gn, 1)
-         + 4 * (size_t)GNS_NPART * (GNS_MAXW + 1) + (size_t)(N + 1) + 5 * (size_t)E;
+         + 4 * (size_t)GNS_NPART * (GNS_MAXW + 1) + (size_t)(N + 1) + 5 * (size_t)E + (size_t)N;
 }
 
 }  // namespace

@@ -26,8 +26,19 @@ def _model(g, device='cuda'):
     return m.to(device)
 
 
+@pytest.fixture(params=['lane-per-grid', 'grid-per-workgroup'])
+def fwd_mapping(request):
+    """Both forward mappings (gns_set_option "fwd_mapping"): 1 = lane per grid, state streamed through HBM;
+    2 = grid per workgroup, state on chip (evaluation-mode calls)."""
+    import opf_graph_neural_solver_amd as amd
+    old = amd.get_option('fwd_mapping')
+    amd.set_option('fwd_mapping', 1 if request.param == 'lane-per-grid' else 2)
+    yield request.param
+    amd.set_option('fwd_mapping', old)
+
+
 @pytest.mark.parametrize('name', golden_names())
-def test_forward_matches_reference_golden(name):
+def test_forward_matches_reference_golden(name, fwd_mapping):
     g = load_golden(name)
     m = _model(g)
     B, L, G = __import__('opf_graph_neural_solver_amd').get_BLG()
@@ -54,10 +65,13 @@ def test_single_grid_2d_api_and_cpu_inputs(name):
 
 
 @pytest.fixture(params=['matrix-pipe', 'packed-fma'])
-def dw_engine(request, monkeypatch):
-    """Both weight-gradient engines of the backward kernel (gns_api.hip reads GNS_DW_MFMA on every call)."""
-    monkeypatch.setenv('GNS_DW_MFMA', '1' if request.param == 'matrix-pipe' else '0')
-    return request.param
+def dw_engine(request):
+    """Both weight-gradient engines of the backward kernel (gns_set_option "dw_mfma")."""
+    import opf_graph_neural_solver_amd as amd
+    old = amd.get_option('dw_mfma')
+    amd.set_option('dw_mfma', 1 if request.param == 'matrix-pipe' else 0)
+    yield request.param
+    amd.set_option('dw_mfma', old)
 
 
 @pytest.mark.parametrize('name', golden_names())
@@ -76,19 +90,50 @@ def test_parameter_gradient_matches_reference_autograd(name, dw_engine):
             assert float(p.grad.abs().max()) == 0.0, n
 
 
+@pytest.mark.parametrize('case,bt,d,multi,K,pack', [(118, 4099, 20, True, 4, 1), (118, 1030, 20, True, 4, 4), (30, 777, 10, False, 3, 3),
+                                                    (14, 2001, 10, True, 2, 16), (300, 130, 20, True, 10, 1), (118, 257, 10, False, 30, 2)])
+def test_forward_mappings_agree_on_large_batches(case, bt, d, multi, K, pack):
+    """Every lane of many workgroups live, ragged last pack, several grids per workgroup: the grid-per-workgroup forward
+    must reproduce the lane-per-grid forward (same arithmetic, other summation order for the per-grid sums: 2e-6)."""
+    import opf_graph_neural_solver_amd as amd
+    bu, li, ge = amd.synth.synth_grids(case, bt, seed=11, device='cuda')
+    torch.manual_seed(0)
+    m = amd.GNS(latent_dim=d, hidden_dim=10, K=K, gamma=0.9, multiple_phi=multi).cuda()
+    old = amd.get_option('fwd_mapping'), amd.get_option('gw_pack')
+    outs = []
+    try:
+        for mapping in (1, 2):
+            amd.set_option('fwd_mapping', mapping)
+            amd.set_option('gw_pack', pack)
+            with torch.no_grad():
+                outs.append([o.double().cpu() for o in m(bu, li, ge)])
+        amd.set_option('fwd_mapping', 2)
+        with torch.no_grad():
+            again = [o.double().cpu() for o in m(bu, li, ge)]
+    finally:
+        amd.set_option('fwd_mapping', old[0])
+        amd.set_option('gw_pack', old[1])
+    for a, b, what in zip(outs[1], outs[0], ('v', 'theta', 'total', 'last')):
+        assert_close(a, b, 2e-6 if K <= 10 else 1e-4, what=what)
+    for a, b in zip(again, outs[1]):
+        assert torch.equal(a, b)                                 # bitwise run-to-run
+
+
 @pytest.mark.parametrize('case,bt,d,multi,K', [(118, 4099, 20, True, 4), (30, 777, 10, False, 3), (14, 20000, 10, True, 2)])
-def test_weight_gradient_engines_agree_on_large_batches(case, bt, d, multi, K, monkeypatch):
+def test_weight_gradient_engines_agree_on_large_batches(case, bt, d, multi, K):
     """The goldens hold <= 4 grids; here every lane of many waves is live: the matrix-pipe contraction and the
     packed-FMA register tiles must give the same gradient up to fp32 summation order (1e-6 of max|grad|)."""
     import opf_graph_neural_solver_amd as amd
     bu, li, ge = amd.synth.synth_grids(case, bt, seed=5, device='cuda')
     grads = []
-    for flag in ('1', '0'):
-        monkeypatch.setenv('GNS_DW_MFMA', flag)
+    old = amd.get_option('dw_mfma')
+    for flag in (1, 0):
+        amd.set_option('dw_mfma', flag)
         torch.manual_seed(0)
         m = amd.GNS(latent_dim=d, hidden_dim=10, K=K, gamma=0.9, multiple_phi=multi).cuda()
         m(bu, li, ge)[2].mean().backward()
         grads.append(torch.cat([p.grad.reshape(-1) for p in m.parameters()]).double().cpu())
+    amd.set_option('dw_mfma', old)
     scale = float(grads[1].abs().max())
     assert scale > 0
     assert float((grads[0] - grads[1]).abs().max()) <= 1e-6 * scale
