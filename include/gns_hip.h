@@ -85,9 +85,11 @@ int gns_forward(const gns_config* cfg, const void* topo_dev, const float* params
  * grad_total / grad_last [Bt] and grad_v / grad_theta [Bt,N] are upstream gradients (any may be NULL = 0).
  * grad_params (flat, state_dict order) is ACCUMULATED into (+=), like autograd does with .grad.
  * L_m.{K-1} (and phi_m.{K-1}) receive exactly zero, matching the reference where they get no gradient.
- * Environment: GNS_DW_MFMA=0 selects the packed-FMA weight-gradient tiles instead of the (exact fp32) matrix-pipe
- * contraction; read on every call, results agree to fp32 summation order. */
-int gns_backward(const gns_config* cfg, const void* topo_dev, const float* params, int64_t Bt,
+ * buses / lines / generators are the tensors the matching gns_forward was given (still owned by the caller, unchanged):
+ * the grid-per-workgroup kernels re-read the batch-constant inputs from them; the lane-per-grid kernels ignore them.
+ * The mapping ("train_mapping", "gw_pack" options) must not change between a forward and its backward. */
+int gns_backward(const gns_config* cfg, const void* topo_dev, const float* params,
+                 const float* buses, const float* lines, const float* generators, int64_t Bt,
                  const void* fwd_workspace, size_t fwd_workspace_bytes,
                  const float* grad_total, const float* grad_last, const float* grad_v, const float* grad_theta,
                  float* grad_params, void* bwd_workspace, size_t bwd_workspace_bytes, void* stream);
@@ -103,9 +105,10 @@ int gns_profile_read(int backward, float* ms_sum, int* launches);
 
 /* ---- configuration (process-wide; set before launching, not concurrently with launches) ------------
  * The library reads its environment ONCE, at the first call of any entry point below or of gns_forward /
- * gns_backward (GNS_FWD_MAPPING=lane|lds, GNS_GW_PACK, GNS_FWD_WAVES, GNS_FWD_PLANE, GNS_DW_MFMA); these
+ * gns_backward (GNS_FWD_MAPPING=lane|lds, GNS_TRAIN_MAPPING=lane|lds, GNS_GW_PACK, GNS_FWD_WAVES, GNS_FWD_PLANE, GNS_DW_MFMA); these
  * setters override those defaults explicitly.  Options:
- *   "fwd_mapping" 0 auto | 1 lane-per-grid kernels (state streamed through HBM) | 2 grid-per-workgroup kernels (state on chip)
+ *   "fwd_mapping" evaluation-mode forward: 0 auto | 1 lane-per-grid kernels (state streamed through HBM) | 2 grid-per-workgroup kernels (state on chip)
+ *   "train_mapping" training-mode forward + backward pair: same values
  *   "gw_pack"     grids per workgroup of the grid-per-workgroup mapping (0 = auto)
  *   "fwd_waves"   waves per workgroup of the lane-per-grid forward (1,2,4,8,16)
  *   "fwd_plane"   0: the lane-per-grid forward gathers neighbour (v, theta) from HBM instead of LDS

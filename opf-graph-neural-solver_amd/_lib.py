@@ -50,7 +50,7 @@ def load_library():
     lib.gns_prepare_topology.argtypes = [i32, i32, i32, vp, vp, vp, vp, sz]
     lib.gns_workspace_bytes.argtypes = [cfgp, i64, ctypes.c_int, ctypes.POINTER(sz), ctypes.POINTER(sz)]
     lib.gns_forward.argtypes = [cfgp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, sz, ctypes.c_int, vp]
-    lib.gns_backward.argtypes = [cfgp, vp, vp, i64, vp, sz, vp, vp, vp, vp, vp, vp, sz, vp]
+    lib.gns_backward.argtypes = [cfgp, vp, vp, vp, vp, vp, i64, vp, sz, vp, vp, vp, vp, vp, vp, sz, vp]
     lib.gns_profile_enable.argtypes = [ctypes.c_int]
     lib.gns_profile_read.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]
     lib.gns_set_option.argtypes = [ctypes.c_char_p, ctypes.c_int]

@@ -15,15 +15,17 @@ struct GnsTuning {
   int fwd_plane;     // GNS_FWD_PLANE=0: lane mapping gathers neighbour (v, theta) from HBM instead of the LDS plane
   int dw_mfma;       // GNS_DW_MFMA=0: packed-FMA weight-gradient engine instead of the matrix pipe
   int gw_ready;      // gns_gw_init_device() succeeded
+  int train_mapping; // GNS_TRAIN_MAPPING: mapping of the training-mode forward + backward pair: 0 auto, 1 lane, 2 lds
 };
 GnsTuning make_tuning() {
-  GnsTuning t{0, 0, GNS_FWD_THREADS / 64, 1, 1, 0};
+  GnsTuning t{0, 0, GNS_FWD_THREADS / 64, 1, 1, 0, 0};
   if (const char* e = std::getenv("GNS_FWD_MAPPING")) t.fwd_mapping = !std::strcmp(e, "lane") ? 1 : (!std::strcmp(e, "lds") ? 2 : 0);
   if (const char* e = std::getenv("GNS_GW_PACK")) { const int p = std::atoi(e); if (p >= 1 && p <= 16) t.gw_pack = p; }
   if (const char* e = std::getenv("GNS_FWD_WAVES")) { const int w = std::atoi(e); if (gns_part_index(w) >= 0 && w * 64 <= GNS_FWD_MAX_THREADS) t.fwd_waves = w; }
   if (const char* e = std::getenv("GNS_FWD_PLANE")) t.fwd_plane = e[0] == '0' ? 0 : 1;
   if (const char* e = std::getenv("GNS_DW_MFMA")) t.dw_mfma = e[0] == '0' ? 0 : 1;
-  t.gw_ready = gns_gw_init_device() == GNS_OK ? 1 : 0;
+  if (const char* e = std::getenv("GNS_TRAIN_MAPPING")) t.train_mapping = !std::strcmp(e, "lane") ? 1 : (!std::strcmp(e, "lds") ? 2 : 0);
+  t.gw_ready = (gns_gw_init_device() == GNS_OK && gns_gw_backward_init_device() == GNS_OK) ? 1 : 0;
   return t;
 }
 GnsTuning& tuning() {
@@ -37,6 +39,7 @@ extern "C" int gns_set_option(const char* name, int value) {
   if (!name) return GNS_EINVAL;
   GnsTuning& t = tuning();
   if (!std::strcmp(name, "fwd_mapping")) { if (value < 0 || value > 2) return GNS_EINVAL; t.fwd_mapping = value; return GNS_OK; }
+  if (!std::strcmp(name, "train_mapping")) { if (value < 0 || value > 2) return GNS_EINVAL; t.train_mapping = value; return GNS_OK; }
   if (!std::strcmp(name, "gw_pack")) { if (value < 0 || value > 16) return GNS_EINVAL; t.gw_pack = value; return GNS_OK; }
   if (!std::strcmp(name, "fwd_waves")) { if (gns_part_index(value) < 0 || value * 64 > GNS_FWD_MAX_THREADS) return GNS_EINVAL; t.fwd_waves = value; return GNS_OK; }
   if (!std::strcmp(name, "fwd_plane")) { t.fwd_plane = value ? 1 : 0; return GNS_OK; }
@@ -47,6 +50,7 @@ extern "C" int gns_get_option(const char* name, int* value) {
   if (!name || !value) return GNS_EINVAL;
   const GnsTuning& t = tuning();
   if (!std::strcmp(name, "fwd_mapping")) *value = t.fwd_mapping;
+  else if (!std::strcmp(name, "train_mapping")) *value = t.train_mapping;
   else if (!std::strcmp(name, "gw_pack")) *value = t.gw_pack;
   else if (!std::strcmp(name, "fwd_waves")) *value = t.fwd_waves;
   else if (!std::strcmp(name, "fwd_plane")) *value = t.fwd_plane;
@@ -83,6 +87,39 @@ void prof_mark(int which, bool start, hipStream_t st) {
   if (!start) ++r.used;
 }
 }  // namespace
+
+// Which mapping runs a training-mode forward and its backward.  Evaluated identically by gns_forward and gns_backward:
+// changing "train_mapping" / "gw_pack" between a forward and its backward is a caller error.
+static int gw_train_pack(const gns_config* c) {
+  const GnsTuning& T = tuning();
+  const int P = T.gw_pack > 0 ? T.gw_pack : 1;
+  if (!T.gw_ready || T.train_mapping != 2) return 0;                 // auto = lane-per-grid until the on-chip pair is the faster one
+  if (!gns_gw_supported(c->n_bus, c->n_line, c->latent_dim, c->hidden_dim, c->multiple_phi, P)) return 0;
+  if (!gns_gw_backward_supported(c->n_bus, c->n_line, c->latent_dim, c->hidden_dim, c->multiple_phi, P)) return 0;
+  return P;
+}
+struct GwTrainLayout { size_t off_pt, off_pn, off_save; GwSaveLayout sv; size_t fwd_total; int blocks, waves; size_t off_slab, off_part, off_tmp, bwd_total; long long slab_floats, nslab; };
+static GwTrainLayout gw_train_layout(const gns_config* c, int64_t Bt, int P) {
+  GwTrainLayout L;
+  GnsFamilies f; gns_families(c->latent_dim, c->hidden_dim, c->K, c->multiple_phi, &f);
+  size_t o = 0;
+  L.off_pt = o; o = gns_align256(o + (size_t)f.t_total * 4);
+  L.off_pn = o; o = gns_align256(o + (size_t)f.n_total * 4);
+  L.off_save = o;
+  L.sv = gw_save_layout(c->n_bus, c->latent_dim, c->hidden_dim, c->K, c->multiple_phi, Bt);
+  L.fwd_total = o + L.sv.total;
+  const int WPG = ((c->n_bus > c->n_line ? c->n_bus : c->n_line) + 63) / 64;
+  L.blocks = gns_gw_backward_blocks(c->n_bus, c->n_line, c->latent_dim, c->hidden_dim, c->multiple_phi, P, Bt);
+  L.waves = P * WPG;
+  L.slab_floats = (f.g_total + 63) / 64 * 64;
+  L.nslab = (long long)L.blocks * L.waves;
+  o = 0;
+  L.off_slab = o; o = gns_align256(o + (size_t)L.nslab * L.slab_floats * 4);
+  L.off_part = o; o = gns_align256(o + (size_t)GNS_RED_PARTS * L.slab_floats * 4);
+  L.off_tmp = o;  o = gns_align256(o + (size_t)L.slab_floats * 4);
+  L.bwd_total = o;
+  return L;
+}
 
 extern "C" int gns_profile_enable(int capacity) {
   for (auto& r : g_prof) {
@@ -135,6 +172,13 @@ extern "C" int gns_workspace_bytes(const gns_config* cfg, int64_t Bt, int save_s
   if (Bt <= 0) return GNS_EINVAL;
   GnsFwdLayout L;
   gns_fwd_layout(cfg->n_bus, cfg->n_line, cfg->latent_dim, cfg->hidden_dim, cfg->K, cfg->multiple_phi, Bt, save_state, &L);
+  const int P = save_state ? gw_train_pack(cfg) : 0;
+  if (P > 0) {
+    const GwTrainLayout G = gw_train_layout(cfg, Bt, P);
+    if (fwd_bytes) *fwd_bytes = G.fwd_total;
+    if (bwd_bytes) *bwd_bytes = G.bwd_total;
+    return GNS_OK;
+  }
   if (fwd_bytes) *fwd_bytes = L.total;
   if (bwd_bytes) {
     GnsBwdLayout B;
@@ -154,16 +198,37 @@ extern "C" int gns_forward(const gns_config* cfg, const void* topo_dev, const fl
     return GNS_EINVAL;
   if (!dims_supported(cfg->latent_dim, cfg->hidden_dim) || cfg->K > GNS_MAX_K) return GNS_EUNSUPPORTED;
   const int N = cfg->n_bus, E = cfg->n_line, Gn = cfg->n_gen, K = cfg->K, d = cfg->latent_dim, h = cfg->hidden_dim;
-  GnsFwdLayout L;
-  gns_fwd_layout(N, E, d, h, K, cfg->multiple_phi, Bt, save_state, &L);
-  if (workspace_bytes < L.total) return GNS_ESIZE;
   GnsFamilies fam; gns_families(d, h, K, cfg->multiple_phi, &fam);
   hipStream_t st = (hipStream_t)stream;
   char* ws = (char*)workspace;
+  const GnsTuning& T = tuning();
+  if (const int TP = save_state ? gw_train_pack(cfg) : 0) {          // training-mode forward of the grid-per-workgroup pair
+    const GwTrainLayout GL = gw_train_layout(cfg, Bt, TP);
+    if (workspace_bytes < GL.fwd_total) return GNS_ESIZE;
+    float* gpt = (float*)(ws + GL.off_pt);
+    float* gpn = (float*)(ws + GL.off_pn);
+    rc = gns_launch_pack_params(params, gpt, gpn, fam, K, d, h, st);
+    if (rc != GNS_OK) return rc;
+    GnsGwFwdArgs G;
+    std::memset(&G, 0, sizeof(G));
+    G.topo = (const int*)topo_dev; G.pt = gpt; G.buses = buses; G.lines = lines; G.gens = generators;
+    G.v_out = v; G.theta_out = theta; G.total_out = total_loss; G.last_out = last_loss;
+    char* sv = ws + GL.off_save;
+    G.sv_state = (float*)(sv + GL.sv.off_state); G.sv_S = (float*)(sv + GL.sv.off_S); G.sv_lam = (float*)(sv + GL.sv.off_lam);
+    for (int i = 0; i < fam.nfam; ++i) { G.t_off[i] = fam.t_off[i]; G.t_sz[i] = fam.t_sz[i]; }
+    for (int k = 0; k < K; ++k) G.gw[k] = (float)std::pow((double)cfg->gamma, (double)(K - k));
+    G.Bt = Bt; G.N = N; G.E = E; G.Gn = Gn; G.K = K; G.save = 1; G.P = TP; G.WPG = ((N > E ? N : E) + 63) / 64;
+    prof_mark(0, true, st);
+    rc = gns_gw_launch_forward(d, h, cfg->multiple_phi, G, st);
+    prof_mark(0, false, st);
+    return rc;
+  }
+  GnsFwdLayout L;
+  gns_fwd_layout(N, E, d, h, K, cfg->multiple_phi, Bt, save_state, &L);
+  if (workspace_bytes < L.total) return GNS_ESIZE;
   float* pt = (float*)(ws + L.off_pt);
   float* pn = (float*)(ws + L.off_pn);
   float* pin = (float*)(ws + L.off_in);
-  const GnsTuning& T = tuning();
   rc = gns_launch_pack_params(params, pt, pn, fam, K, d, h, st);
   if (rc != GNS_OK) return rc;
   // Evaluation (nothing saved for a backward): the grid-per-workgroup mapping keeps the whole state on chip.
@@ -204,7 +269,8 @@ extern "C" int gns_forward(const gns_config* cfg, const void* topo_dev, const fl
   return rc;
 }
 
-extern "C" int gns_backward(const gns_config* cfg, const void* topo_dev, const float* params, int64_t Bt,
+extern "C" int gns_backward(const gns_config* cfg, const void* topo_dev, const float* params,
+                            const float* buses, const float* lines, const float* generators, int64_t Bt,
                             const void* fwd_workspace, size_t fwd_workspace_bytes, const float* grad_total,
                             const float* grad_last, const float* grad_v, const float* grad_theta, float* grad_params,
                             void* bwd_workspace, size_t bwd_workspace_bytes, void* stream) {
@@ -213,6 +279,38 @@ extern "C" int gns_backward(const gns_config* cfg, const void* topo_dev, const f
   if (!topo_dev || !params || !fwd_workspace || !grad_params || !bwd_workspace || Bt <= 0) return GNS_EINVAL;
   if (!dims_supported(cfg->latent_dim, cfg->hidden_dim) || cfg->K > GNS_MAX_K) return GNS_EUNSUPPORTED;
   const int N = cfg->n_bus, E = cfg->n_line, K = cfg->K, d = cfg->latent_dim, h = cfg->hidden_dim;
+  if (const int TP = gw_train_pack(cfg)) {                            // the pair of the grid-per-workgroup training forward
+    if (!buses || !lines || !generators) return GNS_EINVAL;
+    const GwTrainLayout GL = gw_train_layout(cfg, Bt, TP);
+    if (fwd_workspace_bytes < GL.fwd_total || bwd_workspace_bytes < GL.bwd_total) return GNS_ESIZE;
+    GnsFamilies fam; gns_families(d, h, K, cfg->multiple_phi, &fam);
+    hipStream_t st = (hipStream_t)stream;
+    const char* fw = (const char*)fwd_workspace;
+    char* bw = (char*)bwd_workspace;
+    if (hipMemsetAsync(bw + GL.off_slab, 0, (size_t)GL.nslab * GL.slab_floats * 4, st) != hipSuccess) return GNS_ELAUNCH;
+    GnsGwBwdArgs G;
+    std::memset(&G, 0, sizeof(G));
+    G.topo = (const int*)topo_dev;
+    G.pt = (const float*)(fw + GL.off_pt); G.pn = (const float*)(fw + GL.off_pn);
+    G.buses = buses; G.lines = lines; G.gens = generators;
+    const char* sv = fw + GL.off_save;
+    G.sv_state = (const float*)(sv + GL.sv.off_state); G.sv_S = (const float*)(sv + GL.sv.off_S); G.sv_lam = (const float*)(sv + GL.sv.off_lam);
+    G.g_total = grad_total; G.g_last = grad_last; G.g_v = grad_v; G.g_theta = grad_theta;
+    G.slab = (float*)(bw + GL.off_slab);
+    for (int i = 0; i < fam.nfam; ++i) {
+      G.t_off[i] = fam.t_off[i]; G.t_sz[i] = fam.t_sz[i]; G.n_off[i] = fam.n_off[i]; G.n_sz[i] = fam.n_sz[i];
+      G.g_off[i] = fam.g_off[i]; G.g_sz[i] = fam.g_sz[i];
+    }
+    for (int k = 0; k < K; ++k) G.gw[k] = (float)std::pow((double)cfg->gamma, (double)(K - k));
+    G.Bt = Bt; G.slab_floats = GL.slab_floats; G.N = N; G.E = E; G.Gn = cfg->n_gen; G.K = K;
+    G.P = TP; G.WPG = ((N > E ? N : E) + 63) / 64;
+    prof_mark(1, true, st);
+    rc = gns_gw_launch_backward(d, h, cfg->multiple_phi, G, GL.blocks, st);
+    prof_mark(1, false, st);
+    if (rc != GNS_OK) return rc;
+    return gns_launch_reduce(G.slab, (float*)(bw + GL.off_part), (float*)(bw + GL.off_tmp), params, grad_params, GL.nslab,
+                             GL.slab_floats, fam, K, d, h, st);
+  }
   GnsFwdLayout L;
   gns_fwd_layout(N, E, d, h, K, cfg->multiple_phi, Bt, 1, &L);
   GnsBwdLayout B;

@@ -15,399 +15,8 @@
 #include "gns_device.h"
 #include "gns_kernels.h"
 
-// ---- LDS record of one row (one bus or one line of one grid) for one LearningBlock ---------------------
-template <int IN, int H, int OUT>
-struct RecLay {
-  static constexpr int XP = (IN + 1 + 3) / 4 * 4;   // x | 1 | 0..      (the 1 yields the bias gradient)
-  static constexpr int HP = (H + 1 + 3) / 4 * 4;    // a | 1 | 0..  and  g | 0..
-  static constexpr int GP = (OUT + 3) / 4 * 4;      // g3 | 0..
-  static constexpr int oX = 0, oA1 = XP, oA2 = oA1 + HP, oG1 = oA2 + HP, oG2 = oG1 + HP, oG3 = oG2 + HP;
-  static constexpr int raw = oG3 + GP;
-  static constexpr int RS = ((raw / 4) | 1) * 4;    // RS/4 odd: 16-byte row writes of 8 lanes hit 8 different bank quads
-  static constexpr int TX = XP / 4, TH = HP / 4, TG = GP / 4;
-  static constexpr int T1 = TH * TX, T2 = TH * TH, T4 = TG * TH, NT = T1 + T2 + T4;   // 4x4 tiles of dW1|db1, dW2|db2, dW4|db4
-  static_assert(NT <= 64, "one pass per network");
-};
-#define GNS_REC_ROWS 32
-constexpr int gns_cmax(int a, int b) { return a > b ? a : b; }
+#include "gns_dw.h"
 
-template <int IN, int H, int OUT, int OUTP>
-__device__ __forceinline__ void rec_write(float* rec, int row, const f2 (&x)[(IN + 1) / 2], const f2 (&a1)[H / 2], const f2 (&a2)[H / 2],
-                                          const f2 (&g1)[H / 2], const f2 (&g2)[H / 2], const f2 (&g3)[OUTP / 2]) {
-  using R = RecLay<IN, H, OUT>;
-  // 8-byte stores straight from the aligned register pairs the MLPs work on (16-byte stores would first need
-  // four v_mov per store to build a register quad)
-  f2* dst = reinterpret_cast<f2*>(rec + row * R::RS);
-  static_for<0, R::raw / 2>([&](auto q_) {
-    constexpr int q = decltype(q_)::value;
-    constexpr int o = 2 * q;               // even element index; fields start at multiples of 4
-    f2 e;
-    if constexpr (o < R::oA1) {
-      if constexpr (o + 1 < IN) e = x[q];
-      else if constexpr (o < IN) e = f2{x[q].x, 1.f};            // IN odd: last input then the 1 of the bias column
-      else e = (o == IN) ? f2{1.f, 0.f} : f2{0.f, 0.f};
-    } else if constexpr (o < R::oA2) {
-      constexpr int i = o - R::oA1;
-      if constexpr (i < H) e = a1[i / 2]; else e = (i == H) ? f2{1.f, 0.f} : f2{0.f, 0.f};
-    } else if constexpr (o < R::oG1) {
-      constexpr int i = o - R::oA2;
-      if constexpr (i < H) e = a2[i / 2]; else e = (i == H) ? f2{1.f, 0.f} : f2{0.f, 0.f};
-    } else if constexpr (o < R::oG2) {
-      constexpr int i = o - R::oG1;
-      if constexpr (i < H) e = g1[i / 2]; else e = f2{0.f, 0.f};
-    } else if constexpr (o < R::oG3) {
-      constexpr int i = o - R::oG2;
-      if constexpr (i < H) e = g2[i / 2]; else e = f2{0.f, 0.f};
-    } else {
-      constexpr int i = o - R::oG3;
-      if constexpr (i + 1 < OUT) e = g3[i / 2];
-      else if constexpr (i < OUT) e = f2{g3[i / 2].x, 0.f};
-      else e = f2{0.f, 0.f};
-    }
-    dst[q] = e;
-  });
-}
-
-// ---- phi' (two layers): record [x|1, a1|1, g1, g2], tiles of dW1|db1 and dW2|db2 -----------------------------------
-template <int IN, int H>
-struct RecLay2 {
-  static constexpr int XP = (IN + 1 + 3) / 4 * 4, HP = (H + 1 + 3) / 4 * 4;
-  static constexpr int oX = 0, oA1 = XP, oG1 = oA1 + HP, oG2 = oG1 + HP;
-  static constexpr int raw = oG2 + HP;
-  static constexpr int RS = ((raw / 4) | 1) * 4;
-  static constexpr int TX = XP / 4, TH = HP / 4;
-  static constexpr int T1 = TH * TX, T2 = TH * TH, NT = T1 + T2;
-  static_assert(NT <= 64, "one pass per network");
-};
-
-template <int IN, int H>
-__device__ __forceinline__ void rec_write2(float* rec, int row, const f2 (&x)[(IN + 1) / 2], const f2 (&a1)[H / 2],
-                                           const f2 (&g1)[H / 2], const f2 (&g2)[H / 2]) {
-  using R = RecLay2<IN, H>;
-  f2* dst = reinterpret_cast<f2*>(rec + row * R::RS);
-  static_for<0, R::raw / 2>([&](auto q_) {
-    constexpr int q = decltype(q_)::value;
-    constexpr int o = 2 * q;
-    f2 e;
-    if constexpr (o < R::oA1) {
-      if constexpr (o + 1 < IN) e = x[q];
-      else if constexpr (o < IN) e = f2{x[q].x, 1.f};
-      else e = (o == IN) ? f2{1.f, 0.f} : f2{0.f, 0.f};
-    } else if constexpr (o < R::oG1) {
-      constexpr int i = o - R::oA1;
-      if constexpr (i < H) e = a1[i / 2]; else e = (i == H) ? f2{1.f, 0.f} : f2{0.f, 0.f};
-    } else if constexpr (o < R::oG2) {
-      constexpr int i = o - R::oG1;
-      if constexpr (i < H) e = g1[i / 2]; else e = f2{0.f, 0.f};
-    } else {
-      constexpr int i = o - R::oG2;
-      if constexpr (i < H) e = g2[i / 2]; else e = f2{0.f, 0.f};
-    }
-    dst[q] = e;
-  });
-}
-
-// Weight gradient of one LearningBlock for the 64 grids of this wave: dW += sum_grids g (x) input.
-// Lane t < NT owns the 4x4 tile t of [dW1|db1], [dW2|db2] or [dW4|db4]; the tile lives in registers across all
-// the rows (buses / lines) a wave handles in one reverse step and is flushed once, into the wave's slab in the
-// flat layout W1[H][IN] b1[H] W2[H][H] b2[H] W4[OUT][H] b4[OUT].
-struct DwTile { int kind, cb, ib, woff, uoff; };
-
-template <int IN, int H, int OUT>
-__device__ __forceinline__ DwTile dw_tile(int lane) {
-  using R = RecLay<IN, H, OUT>;
-  DwTile T;
-  int t = lane < R::NT ? lane : 0;
-  if (t < R::T1) { T.kind = 0; T.cb = t / R::TX; T.ib = t % R::TX; T.woff = R::oG1 + 4 * T.cb; T.uoff = R::oX + 4 * T.ib; }
-  else if (t < R::T1 + R::T2) { t -= R::T1; T.kind = 1; T.cb = t / R::TH; T.ib = t % R::TH; T.woff = R::oG2 + 4 * T.cb; T.uoff = R::oA1 + 4 * T.ib; }
-  else { t -= R::T1 + R::T2; T.kind = 2; T.cb = t / R::TH; T.ib = t % R::TH; T.woff = R::oG3 + 4 * T.cb; T.uoff = R::oA2 + 4 * T.ib; }
-  return T;
-}
-
-// one half-wave of records is in LDS: every lane adds 32 rank-1 updates to its 4x4 tile
-template <int RS>
-__device__ __forceinline__ void dw_sweep(const float* rec, const DwTile& T, f2 (&acc)[4][2]) {
-  const float* rw = rec + T.woff;
-  const float* ru = rec + T.uoff;
-#ifndef GNS_ABLATE_ENGINE
-#pragma unroll 4
-  for (int r = 0; r < GNS_REC_ROWS; ++r) {
-    const f4 w = *reinterpret_cast<const f4*>(rw + r * RS);
-    const f4 u = *reinterpret_cast<const f4*>(ru + r * RS);
-    const f2 u0 = f2{u.x, u.y}, u1 = f2{u.z, u.w};
-    acc[0][0] = __builtin_elementwise_fma(splat(w.x), u0, acc[0][0]); acc[0][1] = __builtin_elementwise_fma(splat(w.x), u1, acc[0][1]);
-    acc[1][0] = __builtin_elementwise_fma(splat(w.y), u0, acc[1][0]); acc[1][1] = __builtin_elementwise_fma(splat(w.y), u1, acc[1][1]);
-    acc[2][0] = __builtin_elementwise_fma(splat(w.z), u0, acc[2][0]); acc[2][1] = __builtin_elementwise_fma(splat(w.z), u1, acc[2][1]);
-    acc[3][0] = __builtin_elementwise_fma(splat(w.w), u0, acc[3][0]); acc[3][1] = __builtin_elementwise_fma(splat(w.w), u1, acc[3][1]);
-  }
-#else
-  acc[0][0] += f2{rw[0], ru[0]};
-#endif
-}
-
-template <int IN, int H, int OUT, int OUTP>
-__device__ __forceinline__ void dw_accumulate(float* rec, int lane, const DwTile& T, f2 (&acc)[4][2], const f2 (&x)[(IN + 1) / 2],
-                                              const f2 (&a1)[H / 2], const f2 (&a2)[H / 2], const f2 (&g1)[H / 2],
-                                              const f2 (&g2)[H / 2], const f2 (&g3)[OUTP / 2]) {
-  using R = RecLay<IN, H, OUT>;
-#ifdef GNS_ABLATE_DW
-  asm volatile("" :: "v"(x[0]), "v"(a1[0]), "v"(a2[0]), "v"(g1[0]), "v"(g2[0]), "v"(g3[0]));
-  return;
-#endif
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-#ifndef GNS_ABLATE_RECWRITE
-    if ((lane >> 5) == half) rec_write<IN, H, OUT, OUTP>(rec, lane & 31, x, a1, a2, g1, g2, g3);
-#endif
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    dw_sweep<R::RS>(rec, T, acc);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
-}
-
-// phi' needs only 30 tiles, so the two half-waves take the same tiles and sweep one half of the 64 records each:
-// all 64 lanes write their record at once (no masked halves) and the sweep is 32 rows instead of 64.
-template <int IN, int H>
-__device__ __forceinline__ DwTile dw_tile2(int lane) {
-  using R = RecLay2<IN, H>;
-  static_assert(R::NT <= 32, "two half-waves share the tile set");
-  DwTile T;
-  int t = (lane & 31) < R::NT ? (lane & 31) : 0;
-  if (t < R::T1) { T.kind = 0; T.cb = t / R::TX; T.ib = t % R::TX; T.woff = R::oG1 + 4 * T.cb; T.uoff = R::oX + 4 * T.ib; }
-  else { t -= R::T1; T.kind = 1; T.cb = t / R::TH; T.ib = t % R::TH; T.woff = R::oG2 + 4 * T.cb; T.uoff = R::oA1 + 4 * T.ib; }
-  const int half_off = (lane >> 5) * GNS_REC_ROWS * R::RS;      // rows 32..63 for the upper half-wave
-  T.woff += half_off; T.uoff += half_off;
-  return T;
-}
-
-template <int IN, int H>
-__device__ __forceinline__ void dw_accumulate2(float* rec, int lane, const DwTile& T, f2 (&acc)[4][2], const f2 (&x)[(IN + 1) / 2],
-                                               const f2 (&a1)[H / 2], const f2 (&g1)[H / 2], const f2 (&g2)[H / 2]) {
-  using R = RecLay2<IN, H>;
-#ifdef GNS_ABLATE_DW
-  asm volatile("" :: "v"(x[0]), "v"(a1[0]), "v"(g1[0]), "v"(g2[0]));
-  return;
-#endif
-#ifndef GNS_ABLATE_RECWRITE
-  rec_write2<IN, H>(rec, lane, x, a1, g1, g2);
-#endif
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  dw_sweep<R::RS>(rec, T, acc);
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
-
-// phi' tile -> folded-gradient block W1[H][IN] b1[H] W2[H][H] b2[H]
-template <int IN, int H>
-__device__ __forceinline__ void dw_flush2(int lane, const DwTile& T, const f2 (&acc)[4][2], float* slab_blk) {
-  using R = RecLay2<IN, H>;
-  float tot[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int bq = 0; bq < 4; ++bq) {
-      const float v = (bq & 1) ? acc[a][bq >> 1].y : acc[a][bq >> 1].x;
-      tot[a][bq] = v + __shfl_xor(v, 32);                        // rows 0..31 + rows 32..63
-    }
-  if (lane < R::NT) {
-    constexpr int ob1 = IN * H, oW2 = ob1 + H, ob2 = oW2 + H * H;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const int c = 4 * T.cb + a;
-#pragma unroll
-      for (int bq = 0; bq < 4; ++bq) {
-        const int i = 4 * T.ib + bq;
-        const float val = tot[a][bq];
-        int idx = -1;
-        if (T.kind == 0) { if (c < H) idx = (i < IN) ? c * IN + i : (i == IN ? ob1 + c : -1); }
-        else { if (c < H) idx = (i < H) ? oW2 + c * H + i : (i == H ? ob2 + c : -1); }
-        if (idx >= 0) slab_blk[idx] += val;
-      }
-    }
-  }
-}
-
-template <int IN, int H, int OUT>
-__device__ __forceinline__ void dw_flush(int lane, const DwTile& T, const f2 (&acc)[4][2], float* slab_blk) {
-  using R = RecLay<IN, H, OUT>;
-  if (lane < R::NT) {
-    constexpr int ob1 = IN * H, oW2 = ob1 + H, ob2 = oW2 + H * H, oW4 = ob2 + H, ob4 = oW4 + OUT * H;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const int c = 4 * T.cb + a;
-#pragma unroll
-      for (int bq = 0; bq < 4; ++bq) {
-        const int i = 4 * T.ib + bq;
-        const float val = (bq & 1) ? acc[a][bq >> 1].y : acc[a][bq >> 1].x;
-        int idx = -1;
-        if (T.kind == 0) { if (c < H) idx = (i < IN) ? c * IN + i : (i == IN ? ob1 + c : -1); }
-        else if (T.kind == 1) { if (c < H) idx = (i < H) ? oW2 + c * H + i : (i == H ? ob2 + c : -1); }
-        else { if (c < OUT) idx = (i < H) ? oW4 + c * H + i : (i == H ? ob4 + c : -1); }
-        if (idx >= 0) slab_blk[idx] += val;
-      }
-    }
-  }
-}
-
-__device__ __forceinline__ void zero_acc(f2 (&acc)[4][2]) {
-#pragma unroll
-  for (int a = 0; a < 4; ++a) { acc[a][0] = f2{0.f, 0.f}; acc[a][1] = f2{0.f, 0.f}; }
-}
-
-// ---- weight-gradient engines: one object per (network, family sweep) ----------------------------------------------
-// dW = sum over the wave's 64 grids (and its buses / lines) of g (x) input is the one dense contraction of the path.
-// Two interchangeable engines read the same LDS records: MFMA = false keeps 4x4 tiles in registers and uses packed
-// FMAs (GNS_DW_MFMA=0); MFMA = true (default) puts the contraction on the otherwise idle matrix pipe.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-template <int IN, int H, int OUT, int OUTP, bool MFMA>
-struct LEngine;    // three-layer block (L')
-template <int IN, int H, bool MFMA>
-struct PEngine;    // two-layer block (phi')
-
-template <int IN, int H, int OUT, int OUTP>
-struct LEngine<IN, H, OUT, OUTP, false> {
-  DwTile T;
-  f2 acc[4][2];
-  __device__ __forceinline__ void init(int lane) { T = dw_tile<IN, H, OUT>(lane); zero_acc(acc); }
-  __device__ __forceinline__ void accumulate(float* rec, int lane, const f2 (&x)[(IN + 1) / 2], const f2 (&a1)[H / 2], const f2 (&a2)[H / 2],
-                                             const f2 (&g1)[H / 2], const f2 (&g2)[H / 2], const f2 (&g3)[OUTP / 2]) {
-    dw_accumulate<IN, H, OUT, OUTP>(rec, lane, T, acc, x, a1, a2, g1, g2, g3);
-  }
-  __device__ __forceinline__ void flush(int lane, float* slab_blk) { dw_flush<IN, H, OUT>(lane, T, acc, slab_blk); }
-};
-template <int IN, int H>
-struct PEngine<IN, H, false> {
-  DwTile T;
-  f2 acc[4][2];
-  __device__ __forceinline__ void init(int lane) { T = dw_tile2<IN, H>(lane); zero_acc(acc); }
-  __device__ __forceinline__ void accumulate(float* rec, int lane, const f2 (&x)[(IN + 1) / 2], const f2 (&a1)[H / 2],
-                                             const f2 (&g1)[H / 2], const f2 (&g2)[H / 2]) {
-    dw_accumulate2<IN, H>(rec, lane, T, acc, x, a1, g1, g2);
-  }
-  __device__ __forceinline__ void flush(int lane, float* slab_blk) { dw_flush2<IN, H>(lane, T, acc, slab_blk); }
-};
-
-// Matrix-pipe engine: v_mfma_f32_16x16x4_f32 is exact fp32 (no reduced-precision inputs); its k index runs over the
-// grids (rows of the LDS record buffer).  Lane l feeds A[c = l&15][k = l>>4] = g[row 4kk + (l>>4)][cbase + (l&15)] and
-// B[k][i = l&15] = input[row][ibase + (l&15)], and holds D[c = 4*(l>>4) + reg][i = l&15].  Columns past a field's
-// width read the neighbouring field: those products only reach D entries that the flush ignores.  The MLPs themselves
-// stay explicit FMA loops; measured -9..-24 % backward time against the register tiles.
-template <int IN, int H, int OUT, int OUTP>
-struct LEngine<IN, H, OUT, OUTP, true> {
-  using R = RecLay<IN, H, OUT>;
-  static constexpr int NB1 = (R::XP + 15) / 16, NA4 = (R::GP + 15) / 16, NTL = NB1 + 1 + NA4;
-  f32x4 Dacc[NTL];
-  __device__ __forceinline__ void init(int) {
-#pragma unroll
-    for (int t = 0; t < NTL; ++t) Dacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  __device__ __forceinline__ void accumulate(float* rec, int lane, const f2 (&x)[(IN + 1) / 2], const f2 (&a1)[H / 2], const f2 (&a2)[H / 2],
-                                             const f2 (&g1)[H / 2], const f2 (&g2)[H / 2], const f2 (&g3)[OUTP / 2]) {
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      if ((lane >> 5) == half) rec_write<IN, H, OUT, OUTP>(rec, lane & 31, x, a1, a2, g1, g2, g3);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      // k-slot q = l>>4 of step kk reads row 8(kk>>1) + 2(kk&1) + (q>>1) + 4(q&1): the two 16-lane groups the LDS serves
-      // together are 4 rows apart, and 4 RS = 16 (mod 32 banks) for every record stride (RS = 4 mod 8), so their
-      // 16-column windows never share a bank (rows q, q+1 did: SQ_LDS_BANK_CONFLICT was 32 % of the LDS cycles)
-      const float* base = rec + (((lane >> 5) & 1) + 4 * ((lane >> 4) & 1)) * R::RS + (lane & 15);
-      // operands of step kk+1 are read while the matrix pipe works on step kk
-      constexpr int NOP = 4 + NB1 + NA4;
-      float op[2][NOP];
-      auto fetch = [&](float (&o)[NOP], int kk) {
-        const float* b = base + (8 * (kk >> 1) + 2 * (kk & 1)) * R::RS;
-        o[0] = b[R::oG1]; o[1] = b[R::oG2]; o[2] = b[R::oA1]; o[3] = b[R::oA2];
-        static_for<0, NB1>([&](auto t_) { constexpr int t = decltype(t_)::value; o[4 + t] = b[R::oX + 16 * t]; });
-        static_for<0, NA4>([&](auto t_) { constexpr int t = decltype(t_)::value; o[4 + NB1 + t] = b[R::oG3 + 16 * t]; });
-      };
-      fetch(op[0], 0);
-      static_for<0, GNS_REC_ROWS / 4>([&](auto kk_) {
-        constexpr int kk = decltype(kk_)::value;
-        if constexpr (kk + 1 < GNS_REC_ROWS / 4) fetch(op[(kk + 1) & 1], kk + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        const float (&o)[NOP] = op[kk & 1];
-        static_for<0, NB1>([&](auto t_) { constexpr int t = decltype(t_)::value; Dacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(o[0], o[4 + t], Dacc[t], 0, 0, 0); });
-        Dacc[NB1] = __builtin_amdgcn_mfma_f32_16x16x4f32(o[1], o[2], Dacc[NB1], 0, 0, 0);
-        static_for<0, NA4>([&](auto t_) { constexpr int t = decltype(t_)::value; Dacc[NB1 + 1 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(o[4 + NB1 + t], o[3], Dacc[NB1 + 1 + t], 0, 0, 0); });
-        __builtin_amdgcn_sched_barrier(0);
-      });
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-  __device__ __forceinline__ void flush(int lane, float* slab_blk) {
-    constexpr int ob1 = IN * H, oW2 = ob1 + H, ob2 = oW2 + H * H, oW4 = ob2 + H, ob4 = oW4 + OUT * H;
-    const int cl = 4 * (lane >> 4), il = lane & 15;
-    static_for<0, NTL>([&](auto t_) {
-      constexpr int t = decltype(t_)::value;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int c = cl + r;
-        int idx = -1;
-        if constexpr (t < NB1) { const int i = 16 * t + il; if (c < H) idx = (i < IN) ? c * IN + i : (i == IN ? ob1 + c : -1); }
-        else if constexpr (t == NB1) { if (c < H) idx = (il < H) ? oW2 + c * H + il : (il == H ? ob2 + c : -1); }
-        else { const int j = 16 * (t - NB1 - 1) + c; if (j < OUT) idx = (il < H) ? oW4 + j * H + il : (il == H ? ob4 + j : -1); }
-        if (idx >= 0) slab_blk[idx] += Dacc[t][r];
-      }
-    });
-  }
-};
-template <int IN, int H>
-struct PEngine<IN, H, true> {
-  using R = RecLay2<IN, H>;
-  static constexpr int NB1 = (R::XP + 15) / 16, NTL = NB1 + 1;
-  f32x4 Dacc[NTL];
-  __device__ __forceinline__ void init(int) {
-#pragma unroll
-    for (int t = 0; t < NTL; ++t) Dacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  __device__ __forceinline__ void accumulate(float* rec, int lane, const f2 (&x)[(IN + 1) / 2], const f2 (&a1)[H / 2],
-                                             const f2 (&g1)[H / 2], const f2 (&g2)[H / 2]) {
-    rec_write2<IN, H>(rec, lane, x, a1, g1, g2);                 // all 64 records at once
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const float* base = rec + (((lane >> 5) & 1) + 4 * ((lane >> 4) & 1)) * R::RS + (lane & 15);   // row permutation: see LEngine
-    constexpr int NOP = 3 + NB1;
-    float op[2][NOP];
-    auto fetch = [&](float (&o)[NOP], int kk) {
-      const float* b = base + (8 * (kk >> 1) + 2 * (kk & 1)) * R::RS;
-      o[0] = b[R::oG1]; o[1] = b[R::oG2]; o[2] = b[R::oA1];
-      static_for<0, NB1>([&](auto t_) { constexpr int t = decltype(t_)::value; o[3 + t] = b[R::oX + 16 * t]; });
-    };
-    fetch(op[0], 0);
-    static_for<0, 2 * GNS_REC_ROWS / 4>([&](auto kk_) {
-      constexpr int kk = decltype(kk_)::value;
-      if constexpr (kk + 1 < 2 * GNS_REC_ROWS / 4) fetch(op[(kk + 1) & 1], kk + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      const float (&o)[NOP] = op[kk & 1];
-      static_for<0, NB1>([&](auto t_) { constexpr int t = decltype(t_)::value; Dacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(o[0], o[3 + t], Dacc[t], 0, 0, 0); });
-      Dacc[NB1] = __builtin_amdgcn_mfma_f32_16x16x4f32(o[1], o[2], Dacc[NB1], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
-  __device__ __forceinline__ void flush(int lane, float* slab_blk) {
-    constexpr int ob1 = IN * H, oW2 = ob1 + H, ob2 = oW2 + H * H;
-    const int cl = 4 * (lane >> 4), il = lane & 15;
-    static_for<0, NTL>([&](auto t_) {
-      constexpr int t = decltype(t_)::value;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int c = cl + r;
-        int idx = -1;
-        if constexpr (t < NB1) { const int i = 16 * t + il; if (c < H) idx = (i < IN) ? c * IN + i : (i == IN ? ob1 + c : -1); }
-        else { if (c < H) idx = (il < H) ? oW2 + c * H + il : (il == H ? ob2 + c : -1); }
-        if (idx >= 0) slab_blk[idx] += Dacc[t][r];
-      }
-    });
-  }
-};
 
 // ------------------------------------------------------------------------------------------------
 template <int D, int H, bool MULTI, bool MFMA>

@@ -38,7 +38,54 @@ struct GnsGwFwdArgs {
   int P, WPG;                            // grids per workgroup, waves per grid
 };
 
+// ---- saved quantities of a training-mode forward (what the backward re-reads), all in bus-lane order -------------------
+//   state [K+1][Bt][SVQ][N] float4 : (v, theta, dp, dq) + latent vector ENTERING step k; slot K holds row 0 only
+//   S     [K][Bt][NPHI*HQ][N] float4: per phi family the summed hidden vector of the lines ending at the bus
+//   lam   [K][Bt] float2           : (lambda, branch bits)
+struct GwSaveLayout { size_t off_state, off_S, off_lam, total; };
+static inline GwSaveLayout gw_save_layout(int N, int d, int h, int K, int multi, int64_t Bt) {
+  GwSaveLayout L; size_t o = 0;
+  const size_t svq = 1 + (d + 3) / 4, ssq = (size_t)(multi ? 3 : 1) * ((h + 3) / 4);
+  L.off_state = o; o = gns_align256(o + (size_t)(K + 1) * Bt * svq * N * 16);
+  L.off_S = o;     o = gns_align256(o + (size_t)K * Bt * ssq * N * 16);
+  L.off_lam = o;   o = gns_align256(o + (size_t)K * Bt * 8);
+  L.total = o;
+  return L;
+}
+
+struct GwBwdLds { int plane3, slots, gS, u, g1, red, rec, total; };
+GNS_HD static inline GwBwdLds gw_bwd_lds_layout(int N, int E, int H, int WPG, int recf) {
+  GwBwdLds L; int o = 0;
+  L.plane3 = o; o += (3 * N + 3) & ~3;      // (v, theta, dpbar) of the step being reversed      bus -> edge
+  L.slots = o;  o += (6 * E + 3) & ~3;      // per-line physics adjoints                          edge -> bus
+  L.gS = o;     o += (N * H + 3) & ~3;      // adjoint of the hidden-vector sum (one family)      bus -> edge
+  L.u = o;      o += (N * H + 3) & ~3;      // bus share of phi' (one family), recomputed         bus -> edge
+  L.g1 = o;     o += (E * H + 3) & ~3;      // first-layer adjoint of phi' per line               edge -> bus
+  L.red = o;    o += (8 * WPG + 3) & ~3;    // [2 parities][wpg] lambda-adjoint partials + gsum [4][wpg] + pad
+  L.rec = o;    o += WPG * recf;            // per-wave record buffer of the weight-gradient engines
+  L.total = o;
+  return L;
+}
+
+struct GnsGwBwdArgs {
+  const int* topo;
+  const float* pt; const float* pn;
+  const float* buses; const float* lines; const float* gens;
+  const float* sv_state; const float* sv_S; const float* sv_lam;
+  const float* g_total; const float* g_last; const float* g_v; const float* g_theta;   // upstream gradients (nullable)
+  float* slab;                           // [blocks * waves][slab_floats] running weight-gradient sums (zeroed by the caller)
+  long long t_off[6], t_sz[6], n_off[6], n_sz[6], g_off[6], g_sz[6];
+  float gw[GNS_MAX_K];
+  long long Bt, slab_floats;
+  int N, E, Gn, K;
+  int P, WPG;
+};
+
 int gns_gw_launch_forward(int d, int h, int multi, const GnsGwFwdArgs& A, hipStream_t st);
+int gns_gw_launch_backward(int d, int h, int multi, const GnsGwBwdArgs& A, int blocks, hipStream_t st);
+int gns_gw_backward_blocks(int N, int E, int d, int h, int multi, int P, long long Bt);   // persistent grid size (also the slab count / waves)
+int gns_gw_backward_supported(int N, int E, int d, int h, int multi, int P);
 // 1 when the mapping can run this shape (LDS image fits, waves per workgroup <= 16)
 int gns_gw_supported(int N, int E, int d, int h, int multi, int P);
+int gns_gw_backward_init_device(void);
 int gns_gw_init_device(void);            // one-time per process: opt-in to > 64 KB of dynamic LDS for every instantiation

@@ -64,7 +64,7 @@ template <int D, int H, bool MULTI, int MAXT, int MINW>
 __global__ void __launch_bounds__(MAXT, MINW) gns_gw_forward_kernel(GnsGwFwdArgs A) {
   using C = GnsDims<D, H, MULTI>;
   constexpr int NPHI = C::NPHI, UW = NPHI * H, MQ = C::MQ;
-  constexpr int SVQ = 1 + MQ, SSQ = (UW + 3) / 4;
+  constexpr int SVQ = 1 + MQ, HQ = C::HQ, SSQ = NPHI * HQ;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int N = A.N, E = A.E, K = A.K, Gn = A.Gn, WPG = A.WPG, P = A.P;
@@ -194,9 +194,9 @@ __global__ void __launch_bounds__(MAXT, MINW) gns_gw_forward_kernel(GnsGwFwdArgs
         if (A.save && is_bus && live) {
           f4* ss = reinterpret_cast<f4*>(A.sv_S) + ((koff * A.Bt + b) * SSQ) * N + li;
           static_for<0, SSQ>([&](auto q_) {
-            constexpr int q = decltype(q_)::value;
-            f4 t = {S[2 * q].x, S[2 * q].y, 0.f, 0.f};
-            if constexpr (2 * q + 1 < UW / 2) { t.z = S[2 * q + 1].x; t.w = S[2 * q + 1].y; }
+            constexpr int q = decltype(q_)::value, f = q / HQ, r = q % HQ, o = f * (H / 2) + 2 * r;   // family f, float4 row r of its H floats
+            f4 t = {S[o].x, S[o].y, 0.f, 0.f};
+            if constexpr (2 * r + 1 < H / 2) { t.z = S[o + 1].x; t.w = S[o + 1].y; }
             __builtin_nontemporal_store(t, ss + (long long)q * N);
           });
         }
@@ -312,6 +312,8 @@ __global__ void __launch_bounds__(MAXT, MINW) gns_gw_forward_kernel(GnsGwFwdArgs
 
     // ================= epilogue: outputs (main.py:199-202) ===========================================================
     if (bus_wave) {
+      if (A.save && is_bus && live)      // (v, theta, dp)_K for the reverse pass of the last step
+        __builtin_nontemporal_store(f4{sv, sth, sdp, sdq}, reinterpret_cast<f4*>(A.sv_state) + (((long long)K * A.Bt + b) * SVQ) * N + li);
       if (is_bus && live) {
         A.v_out[b * N + n] = (sv < 0.f) ? 0.f : sv;                              // main.py:201
         A.theta_out[b * N + n] = sth;

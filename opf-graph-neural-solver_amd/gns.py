@@ -101,6 +101,7 @@ class _GNSFunction(torch.autograd.Function):
                                ws.data_ptr(), ws.numel(), int(need_grad), stream), 'gns_forward')
         if need_grad:
             ctx.cfg, ctx.topo, ctx.ws, ctx.flat, ctx.Bt, ctx.bwd_bytes = cfg, topo, ws, flat, Bt, bwd_b.value
+            ctx.inputs = (buses, lines, gens)          # the backward of the grid-per-workgroup mapping re-reads them
             ctx.shapes = [p.shape for p in params]
             ctx.flat_version = flat._version
         return v, theta, total, last
@@ -120,7 +121,9 @@ class _GNSFunction(torch.autograd.Function):
 
         keep = [t.contiguous() if t is not None else None for t in (gtot, glast, gv, gth)]
         stream = torch.cuda.current_stream(dev).cuda_stream
-        _check(lib.gns_backward(ctypes.byref(ctx.cfg), ctx.topo.blob.data_ptr(), flat.data_ptr(), ctx.Bt, ctx.ws.data_ptr(),
+        bu, li_, ge = ctx.inputs
+        _check(lib.gns_backward(ctypes.byref(ctx.cfg), ctx.topo.blob.data_ptr(), flat.data_ptr(), bu.data_ptr(), li_.data_ptr(),
+                                ge.data_ptr(), ctx.Bt, ctx.ws.data_ptr(),
                                 ctx.ws.numel(), ptr(keep[0]), ptr(keep[1]), ptr(keep[2]), ptr(keep[3]), grad.data_ptr(),
                                 bws.data_ptr(), bws.numel(), stream), 'gns_backward')
         out, off = [], 0

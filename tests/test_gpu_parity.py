@@ -91,7 +91,7 @@ def test_parameter_gradient_matches_reference_autograd(name, dw_engine):
 
 
 @pytest.mark.parametrize('case,bt,d,multi,K,pack', [(118, 4099, 20, True, 4, 1), (118, 1030, 20, True, 4, 4), (30, 777, 10, False, 3, 3),
-                                                    (14, 2001, 10, True, 2, 16), (300, 130, 20, True, 10, 1), (118, 257, 10, False, 30, 2)])
+                                                    (14, 2001, 10, True, 2, 16), (300, 130, 20, True, 10, 1), (118, 257, 10, True, 15, 2)])
 def test_forward_mappings_agree_on_large_batches(case, bt, d, multi, K, pack):
     """Every lane of many workgroups live, ragged last pack, several grids per workgroup: the grid-per-workgroup forward
     must reproduce the lane-per-grid forward (same arithmetic, other summation order for the per-grid sums: 2e-6)."""
@@ -117,6 +117,60 @@ def test_forward_mappings_agree_on_large_batches(case, bt, d, multi, K, pack):
         assert_close(a, b, 2e-6 if K <= 10 else 1e-4, what=what)
     for a, b in zip(again, outs[1]):
         assert torch.equal(a, b)                                 # bitwise run-to-run
+
+
+@pytest.fixture
+def gw_training():
+    """Training-mode forward + backward on the grid-per-workgroup kernels (gns_set_option "train_mapping" = 2)."""
+    import opf_graph_neural_solver_amd as amd
+    old = amd.get_option('train_mapping'), amd.get_option('gw_pack')
+    amd.set_option('train_mapping', 2)
+    yield amd
+    amd.set_option('train_mapping', old[0])
+    amd.set_option('gw_pack', old[1])
+
+
+@pytest.mark.parametrize('name', golden_names())
+def test_parameter_gradient_matches_reference_autograd_grid_per_workgroup(name, gw_training):
+    """Same check as above for the on-chip mapping: outputs of the training-mode forward and d(mean total_loss)/d(params)
+    against the reference's own forward / .backward() (GNS/main.py:281-288)."""
+    g = load_golden(name)
+    m = _model(g)
+    v, th, tot, last = m(t(g['buses']).cuda(), t(g['lines']).cuda(), t(g['generators']).cuda())
+    assert_close(v.detach().cpu(), g['v'], REL, what='v')
+    assert_close(th.detach().cpu(), g['theta'], REL, what='theta')
+    assert_close(tot.detach().cpu(), g['total_loss'], REL, what='total_loss')
+    tot.mean().backward()
+    grad = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).cpu().numpy()
+    assert_close(grad, g['grad_params'], 5e-5, abs_floor=1e-7, what='grad_params')
+    none = set(str(s) for s in g['none_grad_names'])
+    for n, p in m.named_parameters():
+        if n in none:
+            assert float(p.grad.abs().max()) == 0.0, n
+
+
+@pytest.mark.parametrize('case,bt,d,multi,K,pack', [(118, 1031, 20, True, 4, 1), (118, 259, 20, True, 4, 2), (30, 777, 10, False, 3, 3),
+                                                    (14, 2001, 10, True, 2, 8), (300, 67, 20, True, 3, 1)])
+def test_training_mappings_agree_on_large_batches(case, bt, d, multi, K, pack, gw_training):
+    """Ragged last pack, several grids per workgroup, every upstream gradient (v, theta, total, last) non-zero: the
+    grid-per-workgroup pair must give the lane-per-grid pair's gradient up to fp32 summation order."""
+    amd = gw_training
+    bu, li, ge = amd.synth.synth_grids(case, bt, seed=13, device='cuda')
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    wv, wt = torch.randn(bt, bu.shape[1], device='cuda', generator=gen), torch.randn(bt, bu.shape[1], device='cuda', generator=gen)
+    wl = torch.rand(bt, device='cuda', generator=gen)
+    grads = []
+    for mapping in (1, 2):
+        amd.set_option('train_mapping', mapping)
+        amd.set_option('gw_pack', pack)
+        torch.manual_seed(0)
+        m = amd.GNS(latent_dim=d, hidden_dim=10, K=K, gamma=0.9, multiple_phi=multi).cuda()
+        v, th, tot, last = m(bu, li, ge)
+        (tot.mean() + (v * wv).mean() + (th * wt).mean() + (last * wl).mean()).backward()
+        grads.append(torch.cat([p.grad.reshape(-1) for p in m.parameters()]).double().cpu())
+    scale = float(grads[0].abs().max())
+    assert scale > 0
+    assert float((grads[0] - grads[1]).abs().max()) <= 3e-6 * scale
 
 
 @pytest.mark.parametrize('case,bt,d,multi,K', [(118, 4099, 20, True, 4), (30, 777, 10, False, 3), (14, 20000, 10, True, 2)])
