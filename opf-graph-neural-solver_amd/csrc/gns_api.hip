@@ -233,7 +233,12 @@ extern "C" int gns_forward(const gns_config* cfg, const void* topo_dev, const fl
   if (rc != GNS_OK) return rc;
   // Evaluation (nothing saved for a backward): the grid-per-workgroup mapping keeps the whole state on chip.
   {
-    int P = T.gw_pack > 0 ? T.gw_pack : 1;
+    int P = T.gw_pack;
+    if (P <= 0) {                                   // auto: one workgroup per CU with as many grids as fit (all waves of a CU in the
+      P = 1;                                        // same phase stream the same weights: 73 % scalar-cache hits against 55 %)
+      const int wpg = ((N > E ? N : E) + 63) / 64;
+      for (int q = 2; q * wpg <= 12; ++q) if (gns_gw_supported(N, E, d, h, cfg->multiple_phi, q)) P = q;
+    }
     const bool can = !save_state && T.gw_ready && gns_gw_supported(N, E, d, h, cfg->multiple_phi, P);
     const bool want = T.fwd_mapping == 2 || (T.fwd_mapping == 0 && N >= 48);
     if (can && want) {

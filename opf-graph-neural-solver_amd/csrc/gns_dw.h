@@ -529,3 +529,41 @@ struct GwBusPhiEngine {    // record [m (D, padded to 4) | G1 | 0 0 (12)]: dW1[:
     __builtin_amdgcn_wave_barrier();
   }
 };
+
+// ---- sub-record contraction (grid-per-workgroup backward) ----------------------------------------------------------------
+// Instead of one wide row record per LearningBlock, a wave keeps a [64 rows][12 + 16] window in LDS: an A block (one
+// adjoint vector, <= 12 columns) and a B block (16 input columns).  Every field of a row is written exactly once, by all
+// 64 lanes, then the matrix pipe contracts the window over the rows: D[c][i] += sum_rows A[row][c] B[row][i].
+// 7 KB per wave instead of 14-17, half the LDS store traffic of the half-wave records, same MFMA count.
+struct GwSub {
+  static constexpr int NA = 12, NB = 16, RS = NA + NB, RECF = 64 * RS + 32;   // RS = 28 = 4 (mod 8): see LEngine's row map
+};
+__device__ __forceinline__ void gws_w2r() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+__device__ __forceinline__ void gws_r2w() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+__device__ __forceinline__ void gws_putA(float* rec, int lane, int pair, f2 v) { reinterpret_cast<f2*>(rec + lane * GwSub::RS)[pair] = v; }
+__device__ __forceinline__ void gws_putB(float* rec, int lane, int pair, f2 v) { reinterpret_cast<f2*>(rec + lane * GwSub::RS + GwSub::NA)[pair] = v; }
+template <bool LOADA>
+__device__ __forceinline__ void gws_pass(const float* rec, int lane, float (&Aop)[16], f32x4& Dt) {
+  const float* base = rec + (((lane >> 5) & 1) + 4 * ((lane >> 4) & 1)) * GwSub::RS + (lane & 15);
+  float Bop[16];
+  static_for<0, 16>([&](auto kk_) {
+    constexpr int kk = decltype(kk_)::value;
+    const float* b = base + (8 * (kk >> 1) + 2 * (kk & 1)) * GwSub::RS;
+    if constexpr (LOADA) Aop[kk] = b[0];
+    Bop[kk] = b[GwSub::NA];
+  });
+  static_for<0, 16>([&](auto kk_) {
+    constexpr int kk = decltype(kk_)::value;
+    Dt = __builtin_amdgcn_mfma_f32_16x16x4f32(Aop[kk], Bop[kk], Dt, 0, 0, 0);
+  });
+}
+// slab_blk[idx_of(c, i)] += D[c][i] for the entries that map to a parameter (idx_of returns -1 otherwise)
+template <class F>
+__device__ __forceinline__ void gws_flush(int lane, const f32x4& Dt, float* blk, F&& idx_of) {
+  const int cl = 4 * (lane >> 4), il = lane & 15;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int idx = idx_of(cl + r, il);
+    if (idx >= 0) blk[idx] += Dt[r];
+  }
+}

@@ -55,14 +55,15 @@ static inline GwSaveLayout gw_save_layout(int N, int d, int h, int K, int multi,
 
 struct GwBwdLds { int plane3, slots, gS, u, g1, red, rec, total; };
 GNS_HD static inline GwBwdLds gw_bwd_lds_layout(int N, int E, int H, int WPG, int recf) {
+  // Two regions are shared in time: the per-line physics adjoints (P1 -> P2) live where the first-layer adjoints of phi'
+  // (E -> B') go later in the step, and the (v, theta, dpbar) plane (P0 -> P1) where the hidden-sum adjoints (B -> E) go.
   GwBwdLds L; int o = 0;
-  L.plane3 = o; o += (3 * N + 3) & ~3;      // (v, theta, dpbar) of the step being reversed      bus -> edge
-  L.slots = o;  o += (6 * E + 3) & ~3;      // per-line physics adjoints                          edge -> bus
-  L.gS = o;     o += (N * H + 3) & ~3;      // adjoint of the hidden-vector sum (one family)      bus -> edge
-  L.u = o;      o += (N * H + 3) & ~3;      // bus share of phi' (one family), recomputed         bus -> edge
-  L.g1 = o;     o += (E * H + 3) & ~3;      // first-layer adjoint of phi' per line               edge -> bus
-  L.red = o;    o += (8 * WPG + 3) & ~3;    // [2 parities][wpg] lambda-adjoint partials + gsum [4][wpg] + pad
-  L.rec = o;    o += WPG * recf;            // per-wave record buffer of the weight-gradient engines
+  const int g1f = E * H > 6 * E ? E * H : 6 * E, gSf = N * H > 3 * N ? N * H : 3 * N;
+  L.gS = o; L.plane3 = o; o += (gSf + 3) & ~3;   // bus -> edge
+  L.u = o;      o += (N * H + 3) & ~3;           // bus share of phi' (one family), recomputed         bus -> edge
+  L.g1 = o; L.slots = o; o += (g1f + 3) & ~3;    // edge -> bus
+  L.red = o;    o += (8 * WPG + 3) & ~3;         // [2 parities][wpg] lambda-adjoint partials + gsum [4][wpg] + pad
+  L.rec = o;    o += WPG * recf;                 // per-wave sub-record window of the weight-gradient contraction
   L.total = o;
   return L;
 }

@@ -375,26 +375,45 @@ int gns_gw_init_device(void) {
   return rc;
 }
 
+namespace {
+// resident workgroups per CU for one (instantiation, threads, LDS) combination: asked once from the runtime, then cached
+template <int D, int H, bool MULTI, int MAXT, int MINW>
+int gw_resident_t(int threads, size_t lds) {
+  static int cache_threads = 0, cache_val = 0;
+  static size_t cache_lds = 0;
+  if (cache_val > 0 && cache_threads == threads && cache_lds == lds) return cache_val;
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&gns_gw_forward_kernel<D, H, MULTI, MAXT, MINW>), threads, lds) != hipSuccess || nb < 1) {
+    (void)hipGetLastError();
+    nb = 1;
+  }
+  cache_threads = threads; cache_lds = lds; cache_val = nb;
+  return nb;
+}
+template <int D, int H, bool MULTI, int MAXT, int MINW>
+int gw_go(const GnsGwFwdArgs& A, int threads, size_t lds, hipStream_t st) {
+  // A persistent grid: exactly the workgroups that are resident at once (a second, partial round of workgroups was
+  // measured to leave the waves alive for only 54-75 % of the kernel), each looping over its share of the packs.
+  int per_cu = gw_resident_t<D, H, MULTI, MAXT, MINW>(threads, lds);
+  const int waves = threads / 64;
+  (void)waves;
+  const long long npacks = (A.Bt + A.P - 1) / A.P;
+  const long long cap = (long long)(g_gw_cus > 0 ? g_gw_cus : 256) * per_cu;
+  const int blocks = (int)(npacks < cap ? npacks : cap);
+  return gw_launch_t<D, H, MULTI, MAXT, MINW>(A, blocks, threads, lds, st);
+}
+}  // namespace
+
 int gns_gw_launch_forward(int d, int h, int multi, const GnsGwFwdArgs& A, hipStream_t st) {
   const int threads = A.P * A.WPG * 64;
   const GwLds L = gw_lds_layout(A.N, A.E, (multi ? 3 : 1) * h, A.WPG);
   const size_t lds = (size_t)L.total * 4 * A.P;
   if (threads > 1024 || lds > (size_t)GW_LDS_MAX_BYTES) return GNS_EUNSUPPORTED;
-  const long long npacks = (A.Bt + A.P - 1) / A.P;
-  int per_cu = (int)(GW_LDS_MAX_BYTES / (lds > 0 ? lds : 1));
-  const int by_waves = 16 / (A.P * A.WPG) > 0 ? 16 / (A.P * A.WPG) : 1;       // <= 16 waves per CU at the kernels' register budget
-  if (per_cu > by_waves) per_cu = by_waves;
-  if (per_cu < 1) per_cu = 1;
-  const long long cap = (long long)(g_gw_cus > 0 ? g_gw_cus : 256) * per_cu;
-  const int blocks = (int)(npacks < cap ? npacks : cap);
 #define GNS_CASE(DD, HH)                                                                                       \
   if (d == DD && h == HH) {                                                                                    \
-    if (threads <= 256) return multi ? gw_launch_t<DD, HH, true, 256, 3>(A, blocks, threads, lds, st)           \
-                                     : gw_launch_t<DD, HH, false, 256, 3>(A, blocks, threads, lds, st);         \
-    if (threads <= 768) return multi ? gw_launch_t<DD, HH, true, 768, 1>(A, blocks, threads, lds, st)           \
-                                     : gw_launch_t<DD, HH, false, 768, 1>(A, blocks, threads, lds, st);         \
-    return multi ? gw_launch_t<DD, HH, true, 1024, 1>(A, blocks, threads, lds, st)                              \
-                 : gw_launch_t<DD, HH, false, 1024, 1>(A, blocks, threads, lds, st);                            \
+    if (threads <= 256) return multi ? gw_go<DD, HH, true, 256, 3>(A, threads, lds, st) : gw_go<DD, HH, false, 256, 3>(A, threads, lds, st);   \
+    if (threads <= 768) return multi ? gw_go<DD, HH, true, 768, 1>(A, threads, lds, st) : gw_go<DD, HH, false, 768, 1>(A, threads, lds, st);   \
+    return multi ? gw_go<DD, HH, true, 1024, 1>(A, threads, lds, st) : gw_go<DD, HH, false, 1024, 1>(A, threads, lds, st);                      \
   }
   GNS_FOR_EACH_DIMS(GNS_CASE)
 #undef GNS_CASE

@@ -31,6 +31,14 @@ __device__ __forceinline__ float gb_wave_sum(float v) {
 __device__ __forceinline__ float gb_yof(float r, float x) {
   return __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(__fmul_rn(r, r), __fmul_rn(x, x))));
 }
+// sin / cos on |x| <= pi/4 without range reduction (Cephes single-precision kernels, < 1 ulp)
+__device__ __forceinline__ void gb_sincos_small(float x, float& s, float& c) {
+  const float z = x * x;
+  const float ps = __builtin_fmaf(__builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+  s = __builtin_fmaf(ps * z, x, x);
+  const float pc = __builtin_fmaf(__builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+  c = __builtin_fmaf(pc * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
+}
 template <int NF>
 __device__ __forceinline__ void gb_read_row(const float* row, f2 (&dst)[NF / 2]) {
 #pragma unroll
@@ -78,8 +86,7 @@ struct GwBwdDims {
   using C = GnsDims<D, H, MULTI>;
   using EngE = GwEdgeEngine<C::PHI_IN, H, D>;
   using EngB = GwBusPhiEngine<C::PHI_IN, H, D>;
-  static constexpr int RECF = gb_max(gb_max(GNS_REC_ROWS * RecLay<C::LF_IN, H, D>::RS + 32, GNS_REC_ROWS * RecLay<C::LF_IN, H, 1>::RS + 32),
-                                     gb_max(EngE::RECF, EngB::RECF));
+  static constexpr int RECF = GwSub::RECF;
 };
 
 template <int D, int H, bool MULTI, int MAXT, int MINW>
@@ -218,11 +225,15 @@ __global__ void __launch_bounds__(MAXT, MINW) gns_gw_backward_kernel(GnsGwBwdArg
         const float tha = plane3[3 * ia + 1], thb = plane3[3 * ib + 1], thc = plane3[3 * ic + 1], thd = plane3[3 * id + 1];
         const float dl = tha - thb, dl2 = thd - thc;
         float sA, cA, sB, cB, sD, cD, sC, cC, sD2, cD2;
-        sincosf(ths - tht - dl - shs, &sA, &cA);
-        sincosf(tht - ths - dl + shs, &sB, &cB);
-        sincosf(dl, &sD, &cD);
-        sincosf(tht - ths - dl2 - sht, &sC, &cC);
-        sincosf(dl2, &sD2, &cD2);
+        const float angA = ths - tht - dl - shs, angB = tht - ths - dl + shs, angC = tht - ths - dl2 - sht;
+        const float amax = fmaxf(fmaxf(fmaxf(fabsf(angA), fabsf(angB)), fmaxf(fabsf(angC), fabsf(dl))), fabsf(dl2));
+        if (__builtin_amdgcn_ballot_w64(!(amax <= 0.785f)) == 0) {     // every angle of the wave within pi/4: no range reduction
+          gb_sincos_small(angA, sA, cA); gb_sincos_small(angB, sB, cB); gb_sincos_small(dl, sD, cD);
+          gb_sincos_small(angC, sC, cC); gb_sincos_small(dl2, sD2, cD2);
+        } else {
+          sincosf(angA, &sA, &cA); sincosf(angB, &sB, &cB); sincosf(dl, &sD, &cD);
+          sincosf(angC, &sC, &cC); sincosf(dl2, &sD2, &cD2);
+        }
         // "from" expressions: p_from (main.py:91) and |msg| of the joule loss (main.py:41)
         const float yot = ys / taus, yot2 = ys / (taus * taus);
         const float base = vs * vt * yot;
@@ -326,11 +337,45 @@ __global__ void __launch_bounds__(MAXT, MINW) gns_gw_backward_kernel(GnsGwBwdArg
                   for (int j = 0; j < H / 2; ++j) gSr[j] = f2{0.f, 0.f};
                 }
                 mlp_bwd<C::LF_IN, H, OUTP, 2 * XL, true>(PN + A.n_off[NPHI + l] + koff * A.n_sz[NPHI + l], a1, a2, g3, g2, g1, gx);
-                LEngine<C::LF_IN, H, OUT, OUTP, true> engL;
-                float* blk = slab + A.g_off[NPHI + l] + koff * A.g_sz[NPHI + l];
-                engL.init_from(lane, blk);
-                engL.accumulate(rec, lane, x, a1, a2, g1, g2, g3);
-                engL.store(lane, blk);
+                // ---- weight gradient of L'_l: sub-record windows -> matrix pipe -> the wave's running sums (gns_dw.h) ----
+                {
+                  constexpr int IN = C::LF_IN, ob1 = IN * H, oW2 = ob1 + H, ob2 = oW2 + H * H, oW4 = ob2 + H, ob4 = oW4 + OUT * H;
+                  float* blk = slab + A.g_off[NPHI + l] + koff * A.g_sz[NPHI + l];
+                  float Aop[16];
+                  x[XL - 1].y = 1.f;                                         // column IN of the record: the 1 that yields db1
+                  // dW1 | db1 = sum g1 (x) [x | 1]: three 16-column windows of the input
+                  static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA(rec, lane, j, g1[j]); });
+                  static_for<0, (2 * XL + 15) / 16>([&](auto t_) {
+                    constexpr int t = decltype(t_)::value;
+                    static_for<0, 8>([&](auto j_) { constexpr int j = decltype(j_)::value; if constexpr (8 * t + j < XL) gws_putB(rec, lane, j, x[8 * t + j]); });
+                    gws_w2r();
+                    f32x4 Dt = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (t == 0) gws_pass<true>(rec, lane, Aop, Dt); else gws_pass<false>(rec, lane, Aop, Dt);
+                    gws_r2w();
+                    gws_flush(lane, Dt, blk, [&](int c, int il) { const int i = 16 * t + il; return c < H ? (i < IN ? c * IN + i : (i == IN ? ob1 + c : -1)) : -1; });
+                  });
+                  // dW2 | db2 = sum g2 (x) [a1 | 1]
+                  static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA(rec, lane, j, g2[j]); gws_putB(rec, lane, j, a1[j]); });
+                  gws_putB(rec, lane, H / 2, f2{1.f, 0.f});
+                  gws_w2r();
+                  {
+                    f32x4 Dt = {0.f, 0.f, 0.f, 0.f};
+                    gws_pass<true>(rec, lane, Aop, Dt);
+                    gws_r2w();
+                    gws_flush(lane, Dt, blk, [&](int c, int il) { return c < H ? (il < H ? oW2 + c * H + il : (il == H ? ob2 + c : -1)) : -1; });
+                  }
+                  // dW4 | db4 = sum g3 (x) [a2 | 1], 12 output rows per window
+                  static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putB(rec, lane, j, a2[j]); });
+                  static_for<0, (OUTP + 11) / 12>([&](auto t_) {
+                    constexpr int t = decltype(t_)::value;
+                    static_for<0, 6>([&](auto j_) { constexpr int j = decltype(j_)::value; if constexpr (6 * t + j < OUTP / 2) gws_putA(rec, lane, j, g3[6 * t + j]); });
+                    gws_w2r();
+                    f32x4 Dt = {0.f, 0.f, 0.f, 0.f};
+                    gws_pass<true>(rec, lane, Aop, Dt);
+                    gws_r2w();
+                    gws_flush(lane, Dt, blk, [&](int c, int il) { const int j = 12 * t + c; return (c < 12 && j < OUT) ? (il < H ? oW4 + j * H + il : (il == H ? ob4 + j : -1)) : -1; });
+                  });
+                }
               }
             }
           });
@@ -351,11 +396,25 @@ __global__ void __launch_bounds__(MAXT, MINW) gns_gw_backward_kernel(GnsGwBwdArg
           phi_tail<C::PHI_IN, H, D>(PT + A.t_off[pf] + koff * A.t_sz[pf], uh, xt, a1, a2);
           phi_bwd_hidden<H>(PN + A.n_off[pf] + koff * A.n_sz[pf], a1, a2, gh, g2, g1);
           if (is_edge) gb_write_row<H>(g1_l + li * H, g1);
-          EngE engE;
-          float* blk = slab + A.g_off[pf] + koff * A.g_sz[pf];
-          engE.init_from(lane, blk);
-          engE.accumulate(rec, lane, xt, a1, g1, g2);
-          engE.store(lane, blk);
+          {   // phi' line columns of dW1, db1, dW2, db2 (folded block W1[H][IN] b1[H] W2[H][H] b2[H])
+            constexpr int IN = C::PHI_IN, ob1 = IN * H, oW2 = ob1 + H, ob2 = oW2 + H * H;
+            float* blk = slab + A.g_off[pf] + koff * A.g_sz[pf];
+            float Aop[16];
+            static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA(rec, lane, j, g1[j]); });
+            gws_putB(rec, lane, 0, xt[0]); gws_putB(rec, lane, 1, xt[1]); gws_putB(rec, lane, 2, f2{xt[2].x, 1.f});
+            gws_w2r();
+            f32x4 D1 = {0.f, 0.f, 0.f, 0.f};
+            gws_pass<true>(rec, lane, Aop, D1);
+            gws_r2w();
+            gws_flush(lane, D1, blk, [&](int c, int il) { return c < H ? (il < IN - D ? c * IN + D + il : (il == IN - D ? ob1 + c : -1)) : -1; });
+            static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA(rec, lane, j, g2[j]); gws_putB(rec, lane, j, a1[j]); });
+            gws_putB(rec, lane, H / 2, f2{1.f, 0.f});
+            gws_w2r();
+            f32x4 D2 = {0.f, 0.f, 0.f, 0.f};
+            gws_pass<true>(rec, lane, Aop, D2);
+            gws_r2w();
+            gws_flush(lane, D2, blk, [&](int c, int il) { return c < H ? (il < H ? oW2 + c * H + il : (il == H ? ob2 + c : -1)) : -1; });
+          }
         }
         __syncthreads();
         if (bus_wave && !skip_round) {
@@ -368,11 +427,21 @@ __global__ void __launch_bounds__(MAXT, MINW) gns_gw_backward_kernel(GnsGwBwdArg
             for (int j = 0; j < H / 2; ++j) G1[j] += gr[j];
           }
           phi_bwd_latent<C::PHI_IN, H, D>(PN + A.n_off[pf] + koff * A.n_sz[pf], G1, macc);
-          EngB engB;
-          float* blk = slab + A.g_off[pf] + koff * A.g_sz[pf];
-          engB.init_from(lane, blk);
-          engB.accumulate(rec, lane, m, G1);
-          engB.store(lane, blk);
+          {   // latent columns of phi's dW1: sum over buses G1 (x) m
+            constexpr int IN = C::PHI_IN;
+            float* blk = slab + A.g_off[pf] + koff * A.g_sz[pf];
+            float Aop[16];
+            static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA(rec, lane, j, G1[j]); });
+            static_for<0, (D + 15) / 16>([&](auto t_) {
+              constexpr int t = decltype(t_)::value;
+              static_for<0, 8>([&](auto j_) { constexpr int j = decltype(j_)::value; if constexpr (8 * t + j < D / 2) gws_putB(rec, lane, j, m[8 * t + j]); });
+              gws_w2r();
+              f32x4 Dt = {0.f, 0.f, 0.f, 0.f};
+              if constexpr (t == 0) gws_pass<true>(rec, lane, Aop, Dt); else gws_pass<false>(rec, lane, Aop, Dt);
+              gws_r2w();
+              gws_flush(lane, Dt, blk, [&](int c, int il) { const int i = 16 * t + il; return (c < H && i < D) ? c * IN + i : -1; });
+            });
+          }
         }
       });
       // ---- the adjoints entering step k (identity paths main.py:182,186,188 + what the L' inputs collected) --------
