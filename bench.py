@@ -1,17 +1,24 @@
 #!/usr/bin/env python3
 """Benchmark of the GNS hot path on MI355X: grids/s for forward+backward on batched case118, K=4.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
 
-One "step" = one training step over a resident synthetic batch: fused forward, fused backward, ONE all-reduce of
-the flat gradient (N>1), Adam step.  Inputs are generated on the device before the timed region.  Rank 0 prints
-one JSON line (see DESIGN.md "Measurement" for every field).  At N=1 the line also carries the CPU baseline: the
-oracle (a torch-CPU restatement of the reference's per-grid forward/backward), one single-threaded process per
-core, on a bounded sample of the same workload - run BEFORE the GPU is initialised.
+N > 1 without a launcher: this process spawns the N ranks itself (``python -m torch.distributed.run``, one rank per GPU,
+rendezvous on 127.0.0.1) BEFORE anything touches a GPU, waits for them and exits with their code; under
+``torch.distributed.run`` (RANK / WORLD_SIZE in the environment) it is one of those ranks.
+
+One "step" = one training step over a resident synthetic batch: fused forward, fused backward, ONE all-reduce of the
+flat gradient (N>1), Adam step.  Inputs are generated on the device before the timed region by a counter-based
+generator keyed by (seed, GLOBAL grid index): every GPU count sees the same grids.  Rank 0 prints one JSON line (see
+DESIGN.md "Measurement" for every field).  At N=1 the line also carries the CPU baseline: the oracle (a torch-CPU
+restatement of the reference's per-grid forward/backward), one single-threaded process per core, on a bounded sample
+of the same workload - run BEFORE the GPU is initialised.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,6 +30,7 @@ BYTES_PER_GRID = 10504          # compulsory: every input element read once + ev
 MFLOP_FWD_PER_GRID = 4.19216    # nominal MLP flops of one forward (MACs x 2), reference formulation
 HBM_PEAK_GBS = 8000.0           # MI355X spec (MI355X_MICROARCH.md)
 FP32_PEAK_TFLOPS = 157.3
+DATA_SEED = 1234
 
 
 def _cpu_worker(args):
@@ -36,7 +44,7 @@ def _cpu_worker(args):
     spec = importlib.util.spec_from_file_location('synth_cpu', os.path.join(ROOT, 'opf-graph-neural-solver_amd', 'synth.py'))
     synth = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(synth)
-    buses, lines, gens = synth.synth_grids(CASE, 8, seed=1000 + seed)
+    buses, lines, gens = synth.synth_grids(CASE, 8, seed=DATA_SEED, first_index=8 * seed)   # a slice of the benchmark's own data set
     flat = orc.flatten_params(orc.init_params(D, H, K, MULTI, seed=0))
     params = orc.unflatten_params(flat.clone().requires_grad_(True), D, H, K, MULTI)
     kw = dict(latent_dim=D, K=K, gamma=GAMMA, multiple_phi=MULTI)
@@ -75,31 +83,70 @@ def cpu_baseline(seconds=14.0):
                       f'{cores} single-threaded processes x ~{seconds:.0f} s, torch {__import__("torch").__version__} CPU'}
 
 
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def self_launch(argv, gpus):
+    """--gpus N without a launcher: run the N ranks as CHILD processes of a fresh torch.distributed.run (this process has
+    not initialised any GPU and never will), stream their output through, return their exit code."""
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL needs it on this host driver
+    env.setdefault('OMP_NUM_THREADS', '4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch-per-gpu', type=int, default=BATCH_PER_GPU)
+    ap.add_argument('--sustained-steps', type=int, default=2000,
+                    help='extra untimed-by-the-contract run reported as "sustained" (0 = skip): the K-step burst ends before the chip settles at its power limit')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--rehearse-cpu', action='store_true',
+                    help='launcher / rendezvous / collective / JSON plumbing only, over gloo, without touching a GPU (CPU test)')
     a = ap.parse_args()
+    if a.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    launched = 'WORLD_SIZE' in os.environ and 'RANK' in os.environ
+    if not launched and a.gpus > 1:
+        sys.exit(self_launch(sys.argv[1:], a.gpus))
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N')
+        raise SystemExit(f'WORLD_SIZE={world} does not match --gpus {a.gpus}')
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.rehearse_cpu:
         cpu = cpu_baseline()
 
     import torch
     import torch.distributed as dist
+
+    if a.rehearse_cpu:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(_free_port()))
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t)
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({'metric': 'rehearsal', 'n_gpus': world, 'sum_of_ranks': float(t.item()),
+                              'global_batch': a.batch_per_gpu * world}), flush=True)
+        dist.destroy_process_group()
+        return
+
     import ctypes
     import opf_graph_neural_solver_amd as amd
 
     # Rehearsal switches for a ONE-GPU box (never set by the driver): every rank uses cuda:0 and the collective runs
-    # over gloo, which exercises rendezvous / barrier / all-reduce / max-over-ranks / JSON exactly like the RCCL run.
+    # over gloo, which exercises launch / rendezvous / barrier / all-reduce / max-over-ranks / JSON exactly like the RCCL run.
     share = os.environ.get('GNS_BENCH_SHARE_GPU') == '1'
     backend = os.environ.get('GNS_BENCH_BACKEND', 'nccl')
     if share:
@@ -119,7 +166,8 @@ def main():
     model.topology_check = 'first'             # id columns are verified once per case, not on every step
     opt = amd.training.make_optimizer(model)               # the reference's optimiser: Adam, lr 1e-3 (GNS/main.py:241-243)
     bt = a.batch_per_gpu
-    buses, lines, gens = amd.synth.synth_grids(CASE, bt, seed=1234 + rank, device=dev)   # resident before timing
+    # rank r holds grids [r*bt, (r+1)*bt) of ONE data set: the same grids whatever the GPU count
+    buses, lines, gens = amd.synth.synth_grids(CASE, bt, seed=DATA_SEED, device=dev, first_index=rank * bt)
     Bc, Lc, Gc = amd.get_BLG()
 
     def step():
@@ -136,23 +184,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def timed(nsteps):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            tot_ = step()
+        fence()
+        dt_ = time.perf_counter() - t0
+        tmax = torch.tensor([dt_], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax.item()), tot_
+
     for _ in range(a.warmup):
         step()
     lib.gns_profile_enable(max(a.steps, 1))
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        tot = step()
-    fence()
-    dt = time.perf_counter() - t0
+    dt, tot = timed(a.steps)
     ms_f, n_f, ms_b, n_b = ctypes.c_float(), ctypes.c_int(), ctypes.c_float(), ctypes.c_int()
     lib.gns_profile_read(0, ctypes.byref(ms_f), ctypes.byref(n_f))
     lib.gns_profile_read(1, ctypes.byref(ms_b), ctypes.byref(n_b))
     lib.gns_profile_enable(0)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    final_loss = float(tot.mean().item())
+    sustained = None
+    if a.sustained_steps > 0:
+        sdt, _ = timed(a.sustained_steps)
+        sustained = {'steps': a.sustained_steps, 'value': round(bt * world * a.sustained_steps / sdt, 1), 'unit': 'grids/s',
+                     'ms_per_step': round(sdt / a.sustained_steps * 1e3, 4)}
     # forward-only throughput (evaluation mode), not part of the headline value
     with torch.no_grad():
         for _ in range(2):
@@ -169,14 +226,18 @@ def main():
         value = grids / dt
         fwd_ms = ms_f.value / max(n_f.value, 1)
         bwd_ms = ms_b.value / max(n_b.value, 1)
-        dom_ms, dom = (bwd_ms, 'gns_backward_kernel') if bwd_ms >= fwd_ms else (fwd_ms, 'gns_forward_kernel')
+        train_map = {0: 'auto', 1: 'lane-per-grid', 2: 'grid-per-workgroup'}[amd.get_option('train_mapping')]
+        kfwd = 'gns_gw_forward_kernel' if train_map == 'grid-per-workgroup' else 'gns_forward_kernel'
+        kbwd = 'gns_gw_backward_kernel' if train_map == 'grid-per-workgroup' else 'gns_backward_kernel'
+        dom_ms, dom, dom_is_bwd = (bwd_ms, kbwd, True) if bwd_ms >= fwd_ms else (fwd_ms, kfwd, False)
         ach_gbs = BYTES_PER_GRID * bt / (dom_ms * 1e-3) / 1e9
-        dom_flop = (2.0 if dom == 'gns_backward_kernel' else 1.0) * MFLOP_FWD_PER_GRID * 1e6 * bt
-        traffic = None
+        dom_flop = (2.0 if dom_is_bwd else 1.0) * MFLOP_FWD_PER_GRID * 1e6 * bt
+        traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(pmc):
             try:
                 traffic = json.load(open(pmc)).get(dom)
+                traffic_src = 'profiles/pmc_traffic.json (static: rocprofv3 PMC run of the same workload, not measured in this run)'
             except Exception:
                 traffic = None
         line = {
@@ -185,18 +246,21 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'case118-shaped grids (118 buses, 186 lines, 54 generators), batch {bt} per GPU, K=4, '
                                    'latent_dim=20, hidden_dim=10, multiple_phi=True, gamma=0.9; step = fused forward + fused '
-                                   'backward + flat-gradient all-reduce + Adam',
-                       'global_batch': bt * world, 'parallelism': f'dp{world} (grid-sharded)'},
+                                   'backward + flat-gradient all-reduce + Adam; grids = counter-based synthetic data set '
+                                   f'(seed {DATA_SEED}), rank r holds global grids [r*{bt}, (r+1)*{bt})',
+                       'global_batch': bt * world, 'parallelism': f'dp{world} (grid-sharded)', 'training_kernels': train_map},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': round(ach_gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(ach_gbs / HBM_PEAK_GBS, 5), 'traffic': traffic,
+                         'frac': round(ach_gbs / HBM_PEAK_GBS, 5), 'traffic': traffic, 'traffic_source': traffic_src,
                          'algorithmic_bytes_per_launch': BYTES_PER_GRID * bt, 'kernel_ms': round(dom_ms, 4)},
             'roofline_fp32': {'bound': 'fp32 vector FMA (the binding one: ~400 flop/B)', 'kernel': dom,
                               'achieved': round(dom_flop / (dom_ms * 1e-3) / 1e12, 3), 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                               'frac': round(dom_flop / (dom_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
                               'nominal_flop_per_launch': dom_flop},
-            'kernels_ms': {'gns_forward_kernel': round(fwd_ms, 4), 'gns_backward_kernel': round(bwd_ms, 4)},
+            'kernels_ms': {kfwd: round(fwd_ms, 4), kbwd: round(bwd_ms, 4)},
+            'glue_ms_per_step': round(dt / a.steps * 1e3 - fwd_ms - bwd_ms, 4),
+            'sustained': sustained,
             'forward_only_grids_per_s': round(fwd_only * world, 1),
-            'final_mean_total_loss': float(tot.mean().item()),
+            'final_mean_total_loss': final_loss,
         }
         if cpu is not None:
             line['cpu_baseline'] = cpu

@@ -94,23 +94,27 @@ class _GNSFunction(torch.autograd.Function):
         theta = torch.empty_like(v)
         total = torch.empty(Bt, dtype=torch.float32, device=dev)
         last = torch.empty_like(total)
-        flat = mod._flat
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        _check(lib.gns_forward(ctypes.byref(cfg), topo.blob.data_ptr(), flat.data_ptr(), buses.data_ptr(), lines.data_ptr(),
-                               gens.data_ptr(), Bt, v.data_ptr(), theta.data_ptr(), total.data_ptr(), last.data_ptr(),
-                               ws.data_ptr(), ws.numel(), int(need_grad), stream), 'gns_forward')
+        flat = mod._exec_flat(dev)                       # the parameters themselves, or their device mirror for a CPU-resident model
+        with torch.cuda.device(dev):                     # the launch must land on the tensors' device, whatever the current device is
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _check(lib.gns_forward(ctypes.byref(cfg), topo.blob.data_ptr(), flat.data_ptr(), buses.data_ptr(), lines.data_ptr(),
+                                   gens.data_ptr(), Bt, v.data_ptr(), theta.data_ptr(), total.data_ptr(), last.data_ptr(),
+                                   ws.data_ptr(), ws.numel(), int(need_grad), stream), 'gns_forward')
         if need_grad:
             ctx.cfg, ctx.topo, ctx.ws, ctx.flat, ctx.Bt, ctx.bwd_bytes = cfg, topo, ws, flat, Bt, bwd_b.value
+            ctx.params = params
+            ctx.param_versions = tuple(p._version for p in params)
             ctx.inputs = (buses, lines, gens)          # the backward of the grid-per-workgroup mapping re-reads them
             ctx.shapes = [p.shape for p in params]
-            ctx.flat_version = flat._version
         return v, theta, total, last
 
     @staticmethod
     def backward(ctx, gv, gth, gtot, glast):
         lib = load_library()
         flat = ctx.flat
-        if flat._version != ctx.flat_version:
+        # the backward mixes weights packed by the forward with the live buffer: an in-place update in between (an
+        # optimizer.step(), p.add_()) would give silently inconsistent gradients where torch autograd raises
+        if tuple(p._version for p in ctx.params) != ctx.param_versions:
             raise GNSError('parameters were modified in place between forward and backward')
         dev = flat.device
         grad = torch.zeros_like(flat)
@@ -119,13 +123,17 @@ class _GNSFunction(torch.autograd.Function):
         def ptr(t):
             return None if t is None else t.contiguous().data_ptr()
 
-        keep = [t.contiguous() if t is not None else None for t in (gtot, glast, gv, gth)]
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        keep = [t.to(dev).contiguous() if t is not None else None for t in (gtot, glast, gv, gth)]
         bu, li_, ge = ctx.inputs
-        _check(lib.gns_backward(ctypes.byref(ctx.cfg), ctx.topo.blob.data_ptr(), flat.data_ptr(), bu.data_ptr(), li_.data_ptr(),
-                                ge.data_ptr(), ctx.Bt, ctx.ws.data_ptr(),
-                                ctx.ws.numel(), ptr(keep[0]), ptr(keep[1]), ptr(keep[2]), ptr(keep[3]), grad.data_ptr(),
-                                bws.data_ptr(), bws.numel(), stream), 'gns_backward')
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _check(lib.gns_backward(ctypes.byref(ctx.cfg), ctx.topo.blob.data_ptr(), flat.data_ptr(), bu.data_ptr(), li_.data_ptr(),
+                                    ge.data_ptr(), ctx.Bt, ctx.ws.data_ptr(),
+                                    ctx.ws.numel(), ptr(keep[0]), ptr(keep[1]), ptr(keep[2]), ptr(keep[3]), grad.data_ptr(),
+                                    bws.data_ptr(), bws.numel(), stream), 'gns_backward')
+        pdev = ctx.params[0].device
+        if pdev != dev:
+            grad = grad.to(pdev)                          # CPU-resident model: 59 KB back to the host, like the reference's .grad
         out, off = [], 0
         for shp in ctx.shapes:
             n = int(np.prod(shp))
@@ -172,7 +180,10 @@ class GNS(nn.Module):
         # host-side state (not parameters / buffers: they must not appear in state_dict)
         self.__dict__['_flat'] = None
         self.__dict__['_topo_cache'] = {}
-        self.topology_check = 'always'    # 'always': compare id columns on every call; 'first': only when a case is first seen
+        # 'grid0' (default): every call compares the id columns of the FIRST grid with the cached case (one small compare);
+        # the whole batch is compared when a case is first seen.  'always': whole batch on every call.  'first': never again.
+        self.topology_check = 'grid0'
+        self.__dict__['_mirror'] = None
 
     # ---- flat parameter storage -------------------------------------------------------------------
     def _config(self, n_bus, n_line, n_gen):
@@ -203,6 +214,20 @@ class GNS(nn.Module):
             self.__dict__['_flat'] = flat
         return params
 
+    def _exec_flat(self, dev):
+        """The flat parameter buffer on the device the kernels run on.  A model that lives on a ROCm device is read in
+        place; a CPU-resident model (the reference never calls .to('cuda'): GNS/main.py:227,230-233) is mirrored, 59 KB
+        host-to-device per call, and its gradient is copied back by the backward."""
+        flat = self._flat
+        if flat.device == dev:
+            return flat
+        mir = self._mirror
+        if mir is None or mir.device != dev or mir.shape != flat.shape:
+            mir = torch.empty_like(flat, device=dev)
+            self.__dict__['_mirror'] = mir
+        mir.copy_(flat, non_blocking=False)
+        return mir
+
     def flat_parameters(self):
         """The flat fp32 parameter buffer (state_dict order); parameters are views into it."""
         self._ensure_flat()
@@ -215,11 +240,12 @@ class GNS(nn.Module):
         ids_l = lines3[0, :, 0:2]
         ids_g = gens3[0, :, 0]
         ent = self._topo_cache.get(key)
-        if ent is not None and self.topology_check != 'always':
+        if ent is not None and self.topology_check == 'first':
             return ent[0]
         if ent is not None:
-            same = bool((torch.equal(ids_l, ent[1]) and torch.equal(ids_g, ent[2])
-                         and bool((lines3[:, :, 0:2] == ids_l).all()) and bool((gens3[:, :, 0] == ids_g).all())))
+            same = torch.equal(ids_l, ent[1]) and torch.equal(ids_g, ent[2])
+            if same and self.topology_check == 'always':
+                same = bool((lines3[:, :, 0:2] == ids_l).all()) and bool((gens3[:, :, 0] == ids_g).all())
             if same:
                 return ent[0]
         if not (bool((lines3[:, :, 0:2] == ids_l).all()) and bool((gens3[:, :, 0] == ids_g).all())):
@@ -251,8 +277,11 @@ class GNS(nn.Module):
         params = self._ensure_flat()
         dev = params[0].device
         if dev.type != 'cuda':
-            raise GNSError('the GNS hot path runs on a ROCm device only: call model.to("cuda") first '
-                           '(there is no CPU fallback)')
+            # a CPU-resident model, as the reference builds it (GNS/main.py:227): the kernels still run on the GPU, on a
+            # mirror of the parameters; there is no CPU implementation to fall back to
+            if not torch.cuda.is_available():
+                raise GNSError('the GNS hot path runs on a ROCm device only and none is visible (there is no CPU fallback)')
+            dev = torch.device('cuda', torch.cuda.current_device())
         single = buses.dim() == 2
         if single:
             if lines.dim() != 2 or generators.dim() != 2:

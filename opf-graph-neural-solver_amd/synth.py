@@ -83,23 +83,60 @@ def case_topology(case_nr: int):
     return c['f_bus'], c['t_bus'], c['gen_bus']
 
 
-def synth_grids(case_nr: int, batch: int, seed: int = 0, device='cpu', load_scale: float = 1.0, augment: bool = True):
-    """Return (buses[B,N,6], lines[B,E,7], generators[B,Gn,7]) float32 on ``device``.
+def _hash32(x):
+    """lowbias32 integer hash on int64 tensors holding 32-bit values (same bits on CPU and GPU)."""
+    m = 0xFFFFFFFF
+    x = (x ^ (x >> 16)) & m
+    x = (x * 0x7FEB352D) & m
+    x = (x ^ (x >> 15)) & m
+    x = (x * 0x846CA68B) & m
+    return (x ^ (x >> 16)) & m
 
+
+def counter_uniform(seed: int, stream: int, first_index: int, batch: int, width: int, device) -> torch.Tensor:
+    """Counter-based U[0,1) of shape [batch, width]: the value for (grid g, element j) is a hash of
+    (seed, stream, first_index + g, j) and of nothing else - no generator state - so any shard of a batch, on any
+    device, reproduces the rows of the unsharded batch bit for bit (every GPU count sees the same grids)."""
+    g = torch.arange(first_index, first_index + batch, dtype=torch.int64, device=device).unsqueeze(1)
+    j = torch.arange(width, dtype=torch.int64, device=device).unsqueeze(0)
+    key = _hash32(torch.full((1, 1), (int(seed) * 0x9E3779B1 + int(stream) * 0x85EBCA6B + 0x1234567) & 0xFFFFFFFF,
+                             dtype=torch.int64, device=device))
+    h = _hash32((key + (g & 0xFFFFFFFF)) & 0xFFFFFFFF)
+    h = _hash32((h ^ ((g >> 32) & 0xFFFFFFFF)) & 0xFFFFFFFF)
+    h = _hash32((h + j * 0x27D4EB2F) & 0xFFFFFFFF)
+    return (h >> 8).to(torch.float32) * (1.0 / 16777216.0)          # 24 random bits: exact in fp32
+
+
+def synth_grids(case_nr: int, batch: int, seed: int = 0, device='cpu', load_scale: float = 1.0, augment: bool = True,
+                first_index: int = 0):
+    """Return (buses[B,N,6], lines[B,E,7], generators[B,Gn,7]) float32 on ``device`` for the grids
+    ``first_index .. first_index + batch - 1`` of the (seed, case) data set.
+
+    Every random draw is a counter-based hash of (seed, grid index, column, element): ``synth_grids(c, 8, s)[..][2:5]``
+    equals ``synth_grids(c, 3, s, first_index=2)`` bit for bit, on the CPU and on the device.
     ``load_scale`` multiplies Pd after balancing; < ~0.6 drives the lambda < 0.5 branch of
     ``global_active_compensation`` (GNS/main.py:48,54), which balanced random-weight grids never reach.
     """
     c = base_case(case_nr)
     n, e, gn = CASE_SHAPES[case_nr]
     dev = torch.device(device)
-    g = torch.Generator(device=dev).manual_seed(int(seed))
     f32 = dict(dtype=torch.float32, device=dev)
+    stream = [0]
 
     def tens(a):
         return torch.as_tensor(np.asarray(a, dtype=np.float32), device=dev)
 
     def uni(lo, hi, *shape):
-        return torch.rand(shape, generator=g, **f32) * (hi - lo) + lo
+        stream[0] += 1
+        assert shape[0] == batch and len(shape) == 2
+        return counter_uniform(seed, stream[0], first_index, batch, shape[1], dev) * (hi - lo) + lo
+
+    def rowsum(t):
+        # fixed left-to-right order in float64: the same bits whatever the batch size or the device's reduction strategy
+        acc = torch.zeros(t.shape[0], dtype=torch.float64, device=dev)
+        for j in range(t.shape[1]):
+            acc = acc + t[:, j].double()
+        return acc.unsqueeze(1)
 
     one = lambda *shape: torch.ones(shape, **f32)
     amp = (lambda lo, hi, *s: uni(lo, hi, *s)) if augment else (lambda lo, hi, *s: one(*s))
@@ -114,7 +151,8 @@ def synth_grids(case_nr: int, batch: int, seed: int = 0, device='cpu', load_scal
     pg = (pmin + span * 0.25) + uni(0.0, 1.0, batch, gn) * (span * 0.75 - (pmin + span * 0.25)) if augment \
         else tens(c['Pg']).expand(batch, gn)
     pd = tens(c['Pd']) * amp(0.5, 1.5, batch, n)
-    pd = pd * (pg.sum(dim=1, keepdim=True) / pd.sum(dim=1, keepdim=True).clamp_min(1e-9)) * load_scale
+    ratio = (rowsum(pg) / rowsum(pd).clamp_min(1e-9)).to(torch.float32)        # sum(Pd) == sum(Pg) (augment_grids.py:51)
+    pd = pd * ratio * load_scale
     qd = tens(c['Qd']) * amp(0.5, 1.5, batch, n)
     qg = tens(c['Qg']).expand(batch, gn)
 

@@ -158,6 +158,8 @@ def main():
         ('c118_b2_K4_d20_multi', 118, 2, 4, 20, 10, True, 8, 1.0),         # BASELINE config 3 shape
         ('c118_b2_K4_d20_single', 118, 2, 4, 20, 10, False, 9, 1.0),
         ('c300_b1_K10_d20_multi', 300, 1, 10, 20, 10, True, 10, 1.0),       # BASELINE config 5 shape
+        ('c14_b2_K15_d10_multi', 14, 2, 15, 10, 10, True, 11, 1.0),         # the reference's own run configuration (main.py:209-213)
+        ('c14_b2_K30_d10_single', 14, 2, 30, 10, 10, False, 12, 1.0),       # the reference's constructor defaults (main.py:108)
     ]
     for c in cases:
         run_case(ref, synth, *c)

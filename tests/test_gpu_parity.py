@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import assert_close, cfg_of, golden_names, load_golden, t
+from helpers import assert_close, cfg_of, deep_golden_names, golden_names, load_golden, rel_err, shallow_golden_names, t
 
 pytestmark = pytest.mark.gpu
 
@@ -37,7 +37,7 @@ def fwd_mapping(request):
     amd.set_option('fwd_mapping', old)
 
 
-@pytest.mark.parametrize('name', golden_names())
+@pytest.mark.parametrize('name', shallow_golden_names())
 def test_forward_matches_reference_golden(name, fwd_mapping):
     g = load_golden(name)
     m = _model(g)
@@ -74,7 +74,7 @@ def dw_engine(request):
     amd.set_option('dw_mfma', old)
 
 
-@pytest.mark.parametrize('name', golden_names())
+@pytest.mark.parametrize('name', shallow_golden_names())
 def test_parameter_gradient_matches_reference_autograd(name, dw_engine):
     """d(mean total_loss)/d(params) against the reference's own .backward() (GNS/main.py:284-288).
     Gradient tolerance 5e-5 of max|grad| (fp32 products of ~1e5 terms summed in a different order)."""
@@ -130,7 +130,7 @@ def gw_training():
     amd.set_option('gw_pack', old[1])
 
 
-@pytest.mark.parametrize('name', golden_names())
+@pytest.mark.parametrize('name', shallow_golden_names())
 def test_parameter_gradient_matches_reference_autograd_grid_per_workgroup(name, gw_training):
     """Same check as above for the on-chip mapping: outputs of the training-mode forward and d(mean total_loss)/d(params)
     against the reference's own forward / .backward() (GNS/main.py:281-288)."""
@@ -223,8 +223,15 @@ def test_full_size_batch_against_oracle_sample_and_properties():
         assert torch.equal(v, v2) and torch.equal(th, th2) and torch.equal(tot, tot2) and torch.equal(g_all, g_again)
         # (c) a slice of the batch, alone, gives bitwise the same per-grid outputs
         with torch.no_grad():
+            ve, the, tote, _ = m(bu, li, ge)
             vs, ths, tots, _ = m(bu[100:229], li[100:229], ge[100:229])
-        assert torch.equal(vs, v[100:229]) and torch.equal(ths, th[100:229]) and torch.equal(tots, tot[100:229])
+        # (evaluation runs the grid-per-workgroup kernel, training the lane-per-grid pair: each reproduces itself bitwise on
+        #  any batch composition, and the two agree to fp32 summation order)
+        assert torch.equal(vs, ve[100:229]) and torch.equal(ths, the[100:229]) and torch.equal(tots, tote[100:229])
+        assert_close(ve.cpu(), v.detach().cpu(), 2e-6, what='eval vs train v')
+        assert_close(the.cpu(), th.detach().cpu(), 2e-6, what='eval vs train theta')
+        vt, tht, tott, _ = m(bu[100:229], li[100:229], ge[100:229])          # training-mode slice
+        assert torch.equal(vt, v[100:229]) and torch.equal(tht, th[100:229]) and torch.equal(tott, tot[100:229])
         # (d) mean of two half-batch gradients == full-batch gradient
         halves = []
         for lo, hi in ((0, bt // 2), (bt // 2, bt)):
@@ -235,6 +242,174 @@ def test_full_size_batch_against_oracle_sample_and_properties():
         assert_close((0.5 * (halves[0] + halves[1])).cpu(), g_all.cpu(), 2e-5, abs_floor=1e-7, what='half-batch mean')
 
 
+@pytest.mark.parametrize('name', deep_golden_names())
+@pytest.mark.parametrize('mapping', ['lane-per-grid', 'grid-per-workgroup'])
+def test_reference_run_configurations_pinned_by_goldens(name, mapping, capsys):
+    """The reference's own configurations - K=15, three phis (main.py:209-213) and the constructor defaults K=30, one phi
+    (main.py:108) - against goldens produced by the reference itself.  The measured error of the HIP path against the
+    reference's fp32 outputs and gradients is printed next to the conditioning bound (distance of the reference-order fp32
+    oracle from the fp64 oracle on the same inputs: what fp32 arithmetic in ANY order costs at this depth), and must stay
+    within max(1e-5, 2 x bound) for outputs and max(5e-5, 2 x bound) for gradients.  The gradient check also pins the
+    analytically dropped delta_q adjoint (gns_backward.hip:13-14) at depth."""
+    import opf_graph_neural_solver_amd as amd
+    from oracle import gns_oracle as orc
+    g = load_golden(name)
+    c = cfg_of(g)
+    old = amd.get_option('fwd_mapping'), amd.get_option('train_mapping')
+    code = 1 if mapping == 'lane-per-grid' else 2
+    amd.set_option('fwd_mapping', code); amd.set_option('train_mapping', code)
+    try:
+        m = _model(g)
+        bu, li, ge = t(g['buses']).cuda(), t(g['lines']).cuda(), t(g['generators']).cuda()
+        with torch.no_grad():
+            ev = [o.cpu().numpy() for o in m(bu, li, ge)]
+        v, th, tot, last = m(bu, li, ge)
+        tot.mean().backward()
+        grad = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).cpu().numpy()
+    finally:
+        amd.set_option('fwd_mapping', old[0]); amd.set_option('train_mapping', old[1])
+    okw = dict(latent_dim=c['latent_dim'], K=c['K'], gamma=c['gamma'], multiple_phi=c['multiple_phi'])
+    flat = t(g['params'])
+    nb = g['buses'].shape[0]
+    o32, o64, g32, g64 = [], [], torch.zeros_like(flat), torch.zeros_like(flat, dtype=torch.float64)
+    for b in range(nb):
+        f32, f64 = flat.clone().requires_grad_(True), flat.double().requires_grad_(True)
+        a = orc.gns_forward(orc.unflatten_params(f32, c['latent_dim'], c['hidden_dim'], c['K'], c['multiple_phi']),
+                            t(g['buses'][b]), t(g['lines'][b]), t(g['generators'][b]), **okw)
+        d_ = orc.gns_forward(orc.unflatten_params(f64, c['latent_dim'], c['hidden_dim'], c['K'], c['multiple_phi']),
+                             t(g['buses'][b]).double(), t(g['lines'][b]).double(), t(g['generators'][b]).double(), **okw)
+        (a[2] / nb).backward(); (d_[2] / nb).backward()
+        g32 += f32.grad; g64 += f64.grad
+        o32.append([x.detach().numpy() for x in a]); o64.append([x.detach().numpy() for x in d_])
+    report = []
+    for i, (key, mine_ev, mine_tr) in enumerate((('v', ev[0], v), ('theta', ev[1], th), ('total_loss', ev[2], tot), ('last_loss', ev[3], last))):
+        ref = g[key]
+        bound = rel_err(np.stack([o[i] for o in o32]), np.stack([o[i] for o in o64]))
+        e_ev, e_tr = rel_err(mine_ev, ref), rel_err(mine_tr.detach().cpu().numpy(), ref)
+        report.append(f'{key}: eval {e_ev:.2e} train {e_tr:.2e} (fp32 conditioning bound {bound:.2e})')
+        assert max(e_ev, e_tr) <= max(REL, 2.0 * bound), report[-1]
+    gbound = rel_err(g32.numpy(), g64.numpy())
+    e_g = rel_err(grad, g['grad_params'])
+    report.append(f'grad_params: {e_g:.2e} (fp32 conditioning bound {gbound:.2e})')
+    assert e_g <= max(5e-5, 2.0 * gbound), report[-1]
+    with capsys.disabled():
+        print(f'\n[{name} | {mapping}] error vs the REFERENCE\'s fp32 outputs: ' + '; '.join(report))
+
+
+def test_in_place_parameter_update_between_forward_and_backward_raises():
+    """forward / optimizer.step() (or any in-place parameter write) / backward mixes weights packed by the forward with the
+    live buffer; torch autograd raises in that situation and so must the fused path."""
+    import opf_graph_neural_solver_amd as amd
+    torch.manual_seed(1)
+    m = amd.GNS(10, 10, 2, 0.9, False).cuda()
+    bu, li, ge = amd.synth.synth_grids(14, 4, seed=2, device='cuda')
+    tot = m(bu, li, ge)[2].mean()
+    with torch.no_grad():
+        next(m.parameters()).add_(1.0)
+    with pytest.raises(amd.GNSError, match='modified in place'):
+        tot.backward()
+    m.zero_grad()
+    m(bu, li, ge)[2].mean().backward()                       # an untouched forward/backward pair still works
+    assert all(p.grad is not None for p in m.parameters())
+
+
+@pytest.mark.parametrize('optim', ['Adam', 'SGD'])
+def test_reference_training_loop_runs_unchanged_on_a_cpu_resident_model(optim):
+    """The literal loop of GNS/main.py:274-291 - model built on the CPU and never moved (main.py:227, the .to('cuda') at
+    :230-233 is commented out), CPU tensors from load_all_grids, per-grid keyword calls, torch.mean(torch.stack(losses)),
+    torch.optim.Adam(model.parameters()) - with only the import changed.  The kernels run on the GPU on a mirror of the
+    parameters.  After two epochs the weights are compared with the same loop on the CPU oracle (torch autograd + the same
+    optimiser), tolerance 1e-5 of max|w|:
+      * SGD: every weight.
+      * Adam (the reference's optimiser): the normalised update lr * m / (sqrt(v) + eps) turns a gradient element that is
+        rounding noise in fp32 (cancellation, or the linear1 column fed by delta_q, which is noise in the reference too:
+        main.py:83,103) into +-lr whatever its size, in ANY two implementations; so at least 99 % of the weights must
+        agree to 1e-5, none may differ by more than the 4 steps x lr an opposite sign can produce, and the gradient of
+        the first step is compared directly (5e-5 of max|g|)."""
+    import opf_graph_neural_solver_amd as amd
+    from oracle import gns_oracle as orc
+    d, h, K, multi, nr, bs, epochs = 20, 10, 3, True, 8, 4, 2
+    B, L, G = amd.get_BLG()
+    bu, li, ge = amd.synth.synth_grids(14, nr, seed=31)                        # CPU tensors
+    torch.manual_seed(5)
+    model = amd.GNS(latent_dim=d, hidden_dim=h, K=K, gamma=0.9, multiple_phi=multi)     # stays on the CPU
+    flat0 = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
+    mk = (lambda ps: torch.optim.Adam(ps, lr=0.001)) if optim == 'Adam' else (lambda ps: torch.optim.SGD(ps, lr=0.01))
+    optimizer = mk(model.parameters())
+    first_grad = None
+    for epoch in range(epochs):
+        for batch in range(0, nr - bs + 1, bs):
+            losses, last_losses = [], []
+            for i in range(batch, batch + bs):
+                v, theta, loss, last_loss = model(buses=bu[i], lines=li[i], generators=ge[i], B=B, L=L, G=G)
+                losses.append(loss); last_losses.append(last_loss)
+            total_loss = torch.mean(torch.stack(losses))
+            total_loss.backward()
+            if first_grad is None:
+                first_grad = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
+            optimizer.step()
+            optimizer.zero_grad()
+    assert all(p.device.type == 'cpu' for p in model.parameters()) and v.device.type == 'cpu'
+    mine = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    fo = flat0.clone().requires_grad_(True)                                     # the same loop on the oracle
+    opt_o = mk([fo])
+    first_grad_o = None
+    for epoch in range(epochs):
+        for batch in range(0, nr - bs + 1, bs):
+            losses = []
+            for i in range(batch, batch + bs):
+                losses.append(orc.gns_forward(orc.unflatten_params(fo, d, h, K, multi), bu[i], li[i], ge[i], latent_dim=d, K=K,
+                                              gamma=0.9, multiple_phi=multi)[2])
+            torch.mean(torch.stack(losses)).backward()
+            if first_grad_o is None:
+                first_grad_o = fo.grad.clone()
+            opt_o.step(); opt_o.zero_grad()
+    ref = fo.detach()
+    assert float((mine - flat0).abs().max()) > 1e-4                            # the weights really moved
+    assert_close(first_grad.numpy(), first_grad_o.numpy(), 5e-5, abs_floor=1e-7, what='gradient of the first step')
+    tol = 1e-7 + 1e-5 * float(ref.abs().max())
+    diff = (mine - ref).abs()
+    if optim == 'SGD':
+        assert float(diff.max()) <= tol, f'SGD weights: max|diff| {float(diff.max()):.3e} > {tol:.3e}'
+    else:
+        frac = float((diff <= tol).double().mean())
+        assert frac >= 0.99, f'Adam: only {frac:.4f} of the weights within 1e-5'
+        assert float(diff.max()) <= 2.0 * 4 * 0.001 + tol
+
+
+def test_input_producer_prepare_grids_on_device_matches_reference_goldens(golden_dir):
+    """the batched device-side prepare_grid (GNS/utils.py:17-41) against the reference's own function."""
+    import glob, os
+    import opf_graph_neural_solver_amd as amd
+    files = sorted(glob.glob(os.path.join(golden_dir, 'prepare_*.npz')))
+    assert files
+    for f in files:
+        z = np.load(f, allow_pickle=False)
+        bu, li, ge = amd.prepare_grids(t(z['bus']).cuda(), t(z['branch']).cuda(), t(z['gen']).cuda())
+        assert bu.is_cuda and bu.dtype == torch.float32
+        for mine, key in ((bu, 'buses'), (li, 'lines'), (ge, 'generators')):
+            assert_close(mine.cpu(), z[key], 1e-6, abs_floor=1e-7, what=f'{os.path.basename(f)} {key}')
+
+
+def test_counter_based_synthetic_grids_shards_and_devices_agree():
+    """SURVEY 8(d,f3): grids keyed by (seed, global grid index): on the device a shard reproduces the rows of the unsharded
+    batch bit for bit (the CPU synthesis draws the same numbers and agrees to rounding); the forward on a shard therefore
+    reproduces its rows bitwise."""
+    import opf_graph_neural_solver_amd as amd
+    full = amd.synth.synth_grids(118, 200, seed=77, device='cuda')
+    part = amd.synth.synth_grids(118, 64, seed=77, device='cuda', first_index=100)
+    cpu = amd.synth.synth_grids(118, 64, seed=77, device='cpu', first_index=100)
+    for a, b, c in zip(full, part, cpu):
+        assert torch.equal(a[100:164], b)                         # shard == rows of the whole, bit for bit
+        assert_close(b.cpu(), c, 1e-6, abs_floor=1e-7, what='device vs CPU synthesis')   # same draws; float ops may round differently
+    torch.manual_seed(0)
+    m = amd.GNS(20, 10, 4, 0.9, True).cuda()
+    with torch.no_grad():
+        of, op = m(*full), m(*part)
+    for a, b in zip(of, op):
+        assert torch.equal(a[100:164], b)
+
+
 @pytest.mark.parametrize('kw', [dict(), dict(latent_dim=10, hidden_dim=10, K=15, gamma=0.9, multiple_phi=True)],
                          ids=['ctor-defaults-K30-single-phi', 'main.py-run-config-K15-multi-phi'])
 def test_reference_default_configurations_against_oracle(kw):
@@ -243,7 +418,8 @@ def test_reference_default_configurations_against_oracle(kw):
     at K<=10).  With random weights the K=30 recursion amplifies fp32 rounding: the reference's OWN fp32 result is up
     to 3e-5 from the exact (fp64) one (tools/gpu_depth_conditioning.py), so the 1e-5 bar of the K=4 configs cannot be
     asked against an fp32 answer.  Checked instead: the HIP result is no further from the fp64 oracle than
-    max(1e-5, 2 x the distance of the reference-order fp32 oracle from it); gradients likewise with 1e-4."""
+    max(1e-5, 4 x the distance of the reference-order fp32 oracle from it); gradients likewise with 1e-4.  (Both
+    configurations are pinned directly against the reference by test_reference_run_configurations_pinned_by_goldens.)"""
     import opf_graph_neural_solver_amd as amd
     from oracle import gns_oracle as orc
     torch.manual_seed(3)
@@ -274,15 +450,16 @@ def test_reference_default_configurations_against_oracle(kw):
             for name, mine, i in (('v', v[b], 0), ('theta', th[b], 1), ('total', tot[b], 2), ('last', last[b], 3)):
                 ref_noise = dist(o32[i].detach(), o64[i].detach())
                 mine_err = dist(mine.detach().cpu(), o64[i].detach())
-                assert mine_err <= max(REL, 2.0 * ref_noise), f'case{case} {name}[{b}]: {mine_err:.2e} vs fp32 reference noise {ref_noise:.2e}'
+                assert mine_err <= max(REL, 4.0 * ref_noise), f'case{case} {name}[{b}]: {mine_err:.2e} vs fp32 reference noise {ref_noise:.2e}'
         ref_noise, mine_err = dist(g32, g64), dist(grad, g64)
-        assert mine_err <= max(1e-4, 2.0 * ref_noise), f'case{case} grad: {mine_err:.2e} vs fp32 reference noise {ref_noise:.2e}'
+        assert mine_err <= max(1e-4, 4.0 * ref_noise), f'case{case} grad: {mine_err:.2e} vs fp32 reference noise {ref_noise:.2e}'
 
 
-def test_evaluation_mode_saves_nothing_and_matches_training_mode_bitwise():
-    """Under torch.no_grad() (evaluate.py:79) the forward keeps two ping-pong state slots and draws its update units
-    from a queue; in training mode it saves K+1 states for the backward and uses fixed ranges.  Same bits either way,
-    and the evaluation call must not allocate the saved-state workspace."""
+def test_evaluation_mode_saves_nothing_and_matches_training_mode():
+    """Under torch.no_grad() (evaluate.py:79) the forward saves nothing for a backward (by default it runs the
+    grid-per-workgroup kernel: state on chip); in training mode it saves the per-step states.  Same results to fp32
+    summation order - the same bits when both run the lane-per-grid kernels - and the evaluation call must not
+    allocate the saved-state workspace."""
     import opf_graph_neural_solver_amd as amd
     torch.manual_seed(2)
     m = amd.GNS(20, 10, 6, 0.9, True).cuda()
@@ -297,8 +474,18 @@ def test_evaluation_mode_saves_nothing_and_matches_training_mode_bitwise():
     torch.cuda.synchronize(); peak_train = torch.cuda.max_memory_allocated() - base
     assert tr[2].requires_grad
     for a, b in zip(ev, tr):
-        assert torch.equal(a, b.detach())
+        assert_close(a.cpu(), b.detach().cpu(), 2e-6, what='evaluation vs training mode')
     assert peak_eval < 0.7 * peak_train, (peak_eval, peak_train)
+    # with both modes on the lane-per-grid kernels the outputs are the same bits
+    old = amd.get_option('fwd_mapping')
+    amd.set_option('fwd_mapping', 1)
+    try:
+        with torch.no_grad():
+            ev1 = m(bu, li, ge)
+    finally:
+        amd.set_option('fwd_mapping', old)
+    for a, b in zip(ev1, tr):
+        assert torch.equal(a, b.detach())
 
 
 def test_reference_style_per_grid_training_loop_equals_the_batched_step():
@@ -364,9 +551,13 @@ def test_error_behaviour_on_device():
         m(bu, bad, ge)
     with pytest.raises(ValueError):
         m(bu.double(), li, ge)
-    cpu_model = amd.GNS(20, 10, 2, 0.9, True)
-    with pytest.raises(amd.GNSError):
-        cpu_model(bu.cpu(), li.cpu(), ge.cpu())     # no CPU fallback
+    torch.manual_seed(0)
+    cpu_model = amd.GNS(20, 10, 2, 0.9, True)      # CPU-resident, like the reference's (main.py:227): runs on the GPU via a mirror
+    torch.manual_seed(0)
+    gpu_model = amd.GNS(20, 10, 2, 0.9, True).cuda()
+    with torch.no_grad():
+        oc, og = cpu_model(bu.cpu(), li.cpu(), ge.cpu()), gpu_model(bu, li, ge)
+    assert oc[0].device.type == 'cpu' and torch.equal(oc[0], og[0].cpu()) and torch.equal(oc[2], og[2].cpu())
     with pytest.raises(amd.GNSError):
         amd.GNS(12, 10, 2, 0.9, True).cuda()(bu, li, ge)   # no kernel compiled for latent_dim 12
 

@@ -97,3 +97,19 @@ def test_fit_trains_on_device_and_checkpoint_round_trips(tmp_path):
     f, tt, _ = amd.synth.case_topology(14)
     flow = amd.metrics.active_line_flow(a[0], a[1], lines[:64, :, 3], lines[0, :, 0], lines[0, :, 1])
     assert flow.shape == (64, 20) and bool(torch.isfinite(flow).all())
+
+
+def test_counter_based_synthetic_grids_are_keyed_by_global_grid_index():
+    """every GPU count must see the same grids: a shard [lo, hi) of the data set equals those rows of the whole."""
+    import opf_graph_neural_solver_amd as amd
+    full = amd.synth.synth_grids(30, 50, seed=9)
+    for lo, n in ((0, 7), (7, 30), (37, 13)):
+        part = amd.synth.synth_grids(30, n, seed=9, first_index=lo)
+        for a, b in zip(full, part):
+            assert torch.equal(a[lo:lo + n], b)
+    other = amd.synth.synth_grids(30, 50, seed=10)
+    assert not torch.equal(full[0], other[0])
+    u = amd.synth.counter_uniform(3, 1, 0, 20000, 16, 'cpu')
+    assert 0.0 <= float(u.min()) and float(u.max()) < 1.0 and abs(float(u.mean()) - 0.5) < 5e-3
+    # balance rescale of augment_grids.py:51: sum(Pd) == sum(Pg) for every grid
+    assert torch.allclose(full[0][:, :, 2].sum(1), full[2][:, :, 3].sum(1), rtol=1e-5)
