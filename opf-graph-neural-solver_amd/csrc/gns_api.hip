@@ -108,7 +108,7 @@ static GwTrainLayout gw_train_layout(const gns_config* c, int64_t Bt, int P) {
   L.off_save = o;
   L.sv = gw_save_layout(c->n_bus, c->latent_dim, c->hidden_dim, c->K, c->multiple_phi, Bt);
   L.fwd_total = o + L.sv.total;
-  const int WPG = ((c->n_bus > c->n_line ? c->n_bus : c->n_line) + 63) / 64;
+  const int WPG = gns_gw_backward_wpg(c->n_bus);
   L.blocks = gns_gw_backward_blocks(c->n_bus, c->n_line, c->latent_dim, c->hidden_dim, c->multiple_phi, P, Bt);
   L.waves = P * WPG;
   L.slab_floats = (f.g_total + 63) / 64 * 64;
@@ -308,7 +308,7 @@ extern "C" int gns_backward(const gns_config* cfg, const void* topo_dev, const f
     }
     for (int k = 0; k < K; ++k) G.gw[k] = (float)std::pow((double)cfg->gamma, (double)(K - k));
     G.Bt = Bt; G.slab_floats = GL.slab_floats; G.N = N; G.E = E; G.Gn = cfg->n_gen; G.K = K;
-    G.P = TP; G.WPG = ((N > E ? N : E) + 63) / 64;
+    G.P = TP; G.WPG = gns_gw_backward_wpg(N);
     prof_mark(1, true, st);
     rc = gns_gw_launch_backward(d, h, cfg->multiple_phi, G, GL.blocks, st);
     prof_mark(1, false, st);

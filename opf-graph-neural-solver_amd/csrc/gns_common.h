@@ -83,10 +83,18 @@ GNS_HD static inline int64_t gns_t_block(bool is_phi, int d, int h, int out) {
   int in = gns_lin(d, h), op = out + (out & 1);
   return gns_pad16((int64_t)in * h + h + (int64_t)h * h + h + (int64_t)h * op + op);
 }
-GNS_HD static inline int64_t gns_n_block(bool is_phi, int d, int h, int out) {
-  if (is_phi) { int in = d + 5, ip = in + (in & 1); return gns_pad16((int64_t)h * h + (int64_t)h * ip); }
+// The N-stream blocks end with a second copy of the first-layer weights in "input-major" order, W1x[groups of 4 inputs][H][4]
+// (zero beyond the used inputs): the grid-per-workgroup backward produces the input adjoints 4 at a time from it and
+// hands each finished pair on at once, instead of holding all of them until the last weight row has been streamed.
+// phi' keeps only the latent columns there (the line parameters get no adjoint).
+GNS_HD static inline int gns_w1x_groups(bool is_phi, int d, int h) { return is_phi ? (d + 3) / 4 : (gns_lin(d, h) + 3) / 4; }
+GNS_HD static inline int64_t gns_n_w1x_off(bool is_phi, int d, int h, int out) {    // offset of W1x inside an N-stream block
+  if (is_phi) { int in = d + 5, ip = in + (in & 1); return (int64_t)h * h + (int64_t)h * ip; }
   int in = gns_lin(d, h), ip = in + (in & 1), op = out + (out & 1);
-  return gns_pad16((int64_t)op * h + (int64_t)h * h + (int64_t)h * ip);
+  return (int64_t)op * h + (int64_t)h * h + (int64_t)h * ip;
+}
+GNS_HD static inline int64_t gns_n_block(bool is_phi, int d, int h, int out) {
+  return gns_pad16(gns_n_w1x_off(is_phi, d, h, out) + (int64_t)gns_w1x_groups(is_phi, d, h) * h * 4);
 }
 
 struct GnsFamilies {   // per network family (phi*, L_theta, L_v, L_m) in state_dict order

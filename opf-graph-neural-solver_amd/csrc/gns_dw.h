@@ -542,19 +542,23 @@ __device__ __forceinline__ void gws_w2r() { __builtin_amdgcn_fence(__ATOMIC_RELE
 __device__ __forceinline__ void gws_r2w() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 __device__ __forceinline__ void gws_putA(float* rec, int lane, int pair, f2 v) { reinterpret_cast<f2*>(rec + lane * GwSub::RS)[pair] = v; }
 __device__ __forceinline__ void gws_putB(float* rec, int lane, int pair, f2 v) { reinterpret_cast<f2*>(rec + lane * GwSub::RS + GwSub::NA)[pair] = v; }
-template <bool LOADA>
-__device__ __forceinline__ void gws_pass(const float* rec, int lane, float (&Aop)[16], f32x4& Dt) {
+// One contraction pass over the window, in two halves of 8 k-steps (16 operand registers in flight instead of 32)
+__device__ __forceinline__ void gws_pass(const float* rec, int lane, f32x4& Dt) {
   const float* base = rec + (((lane >> 5) & 1) + 4 * ((lane >> 4) & 1)) * GwSub::RS + (lane & 15);
-  float Bop[16];
-  static_for<0, 16>([&](auto kk_) {
-    constexpr int kk = decltype(kk_)::value;
-    const float* b = base + (8 * (kk >> 1) + 2 * (kk & 1)) * GwSub::RS;
-    if constexpr (LOADA) Aop[kk] = b[0];
-    Bop[kk] = b[GwSub::NA];
-  });
-  static_for<0, 16>([&](auto kk_) {
-    constexpr int kk = decltype(kk_)::value;
-    Dt = __builtin_amdgcn_mfma_f32_16x16x4f32(Aop[kk], Bop[kk], Dt, 0, 0, 0);
+  static_for<0, 2>([&](auto h_) {
+    constexpr int hh = decltype(h_)::value;
+    float Aop[8], Bop[8];
+    static_for<0, 8>([&](auto kk_) {
+      constexpr int kk = 8 * hh + decltype(kk_)::value;
+      const float* b = base + (8 * (kk >> 1) + 2 * (kk & 1)) * GwSub::RS;
+      Aop[kk - 8 * hh] = b[0];
+      Bop[kk - 8 * hh] = b[GwSub::NA];
+    });
+    static_for<0, 8>([&](auto kk_) {
+      constexpr int kk = decltype(kk_)::value;
+      Dt = __builtin_amdgcn_mfma_f32_16x16x4f32(Aop[kk], Bop[kk], Dt, 0, 0, 0);
+    });
+    __builtin_amdgcn_sched_barrier(0);
   });
 }
 // slab_blk[idx_of(c, i)] += D[c][i] for the entries that map to a parameter (idx_of returns -1 otherwise)
@@ -565,5 +569,15 @@ __device__ __forceinline__ void gws_flush(int lane, const f32x4& Dt, float* blk,
   for (int r = 0; r < 4; ++r) {
     const int idx = idx_of(cl + r, il);
     if (idx >= 0) blk[idx] += Dt[r];
+  }
+}
+// stage[idx_of(c, i)] = D[c][i]: the wave's LDS stage of a gradient block (every entry is produced exactly once per use)
+template <class F>
+__device__ __forceinline__ void gws_stage(int lane, const f32x4& Dt, float* stage, F&& idx_of) {
+  const int cl = 4 * (lane >> 4), il = lane & 15;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int idx = idx_of(cl + r, il);
+    if (idx >= 0) stage[idx] = Dt[r];
   }
 }

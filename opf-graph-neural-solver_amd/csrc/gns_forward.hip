@@ -33,6 +33,7 @@ __global__ void gns_pack_params_kernel(const float* __restrict__ flat, float* __
       float v = 0.f;
       if (e < nW1) v = src[sW2 + e];
       else if (e < nt) { int q = e - nW1, j = q / INP, i = q % INP; v = i < IN ? src[sW1 + j * IN + i] : 0.f; }
+      else { int q = e - nt, g = q / (4 * H), j = (q % (4 * H)) / 4, i = 4 * g + (q & 3); v = (g < (D + 3) / 4 && i < D) ? src[sW1 + j * IN + i] : 0.f; }   // W1x: latent columns
       n[e] = v;
     }
     return;
@@ -69,6 +70,7 @@ __global__ void gns_pack_params_kernel(const float* __restrict__ flat, float* __
     if (e < nW2) { int j = e / H, i = e % H; v = j < OUT ? src[sW4 + j * H + i] : 0.f; }
     else if (e < nW1) v = src[sW2 + (e - nW2)];
     else if (e < nt) { int q = e - nW1, j = q / INFP, i = q % INFP; v = i < INF ? w1f(j, i) : 0.f; }
+    else { int q = e - nt, g = q / (4 * H), j = (q % (4 * H)) / 4, i = 4 * g + (q & 3); v = (g < (INF + 3) / 4 && i < INF) ? w1f(j, i) : 0.f; }   // W1x
     n[e] = v;
   }
 }

@@ -53,8 +53,8 @@ static inline GwSaveLayout gw_save_layout(int N, int d, int h, int K, int multi,
   return L;
 }
 
-struct GwBwdLds { int plane3, slots, gS, u, g1, red, rec, total; };
-GNS_HD static inline GwBwdLds gw_bwd_lds_layout(int N, int E, int H, int WPG, int recf) {
+struct GwBwdLds { int plane3, slots, gS, u, g1, red, ylds, rec, stage, total; };
+GNS_HD static inline GwBwdLds gw_bwd_lds_layout(int N, int E, int H, int WPG, int recf, int stgf) {
   // Two regions are shared in time: the per-line physics adjoints (P1 -> P2) live where the first-layer adjoints of phi'
   // (E -> B') go later in the step, and the (v, theta, dpbar) plane (P0 -> P1) where the hidden-sum adjoints (B -> E) go.
   GwBwdLds L; int o = 0;
@@ -63,7 +63,9 @@ GNS_HD static inline GwBwdLds gw_bwd_lds_layout(int N, int E, int H, int WPG, in
   L.u = o;      o += (N * H + 3) & ~3;           // bus share of phi' (one family), recomputed         bus -> edge
   L.g1 = o; L.slots = o; o += (g1f + 3) & ~3;    // edge -> bus
   L.red = o;    o += (8 * WPG + 3) & ~3;         // [2 parities][wpg] lambda-adjoint partials + gsum [4][wpg] + pad
+  L.ylds = o;   o += (E + 3) & ~3;               // y = 1/sqrt(r^2+x^2) per line number, once per grid
   L.rec = o;    o += WPG * recf;                 // per-wave sub-record window of the weight-gradient contraction
+  L.stage = o;  o += WPG * stgf;                 // per-wave stage of one gradient block between the matrix pipe and the slab
   L.total = o;
   return L;
 }
@@ -86,6 +88,7 @@ int gns_gw_launch_forward(int d, int h, int multi, const GnsGwFwdArgs& A, hipStr
 int gns_gw_launch_backward(int d, int h, int multi, const GnsGwBwdArgs& A, int blocks, hipStream_t st);
 int gns_gw_backward_blocks(int N, int E, int d, int h, int multi, int P, long long Bt);   // persistent grid size (also the slab count / waves)
 int gns_gw_backward_supported(int N, int E, int d, int h, int multi, int P);
+int gns_gw_backward_wpg(int N);             // waves per grid of the backward: ceil(N / 64); a lane takes up to two lines
 // 1 when the mapping can run this shape (LDS image fits, waves per workgroup <= 16)
 int gns_gw_supported(int N, int E, int d, int h, int multi, int P);
 int gns_gw_backward_init_device(void);
