@@ -188,8 +188,28 @@ extern "C" int gns_workspace_bytes(const gns_config* cfg, int64_t Bt, int save_s
   return GNS_OK;
 }
 
+extern "C" int gns_prepack_bytes(const gns_config* cfg, int64_t Bt, size_t* bytes) {
+  int rc = check_cfg(cfg);
+  if (rc != GNS_OK) return rc;
+  if (!bytes || Bt <= 0) return GNS_EINVAL;
+  const int64_t groups = (Bt + GNS_LANES - 1) / GNS_LANES;
+  *bytes = (size_t)groups * gns_in_rows(cfg->n_bus, cfg->n_line) * GNS_LANES * 16;
+  return GNS_OK;
+}
+
+extern "C" int gns_prepack(const gns_config* cfg, const void* topo_dev, const float* buses, const float* lines,
+                           const float* generators, int64_t Bt, void* packed, size_t packed_bytes, void* stream) {
+  size_t need = 0;
+  int rc = gns_prepack_bytes(cfg, Bt, &need);
+  if (rc != GNS_OK) return rc;
+  if (!topo_dev || !buses || !lines || !generators || !packed) return GNS_EINVAL;
+  if (packed_bytes < need) return GNS_ESIZE;
+  return gns_launch_pack_inputs((const int*)topo_dev, buses, lines, generators, (float*)packed, cfg->n_bus, cfg->n_line, cfg->n_gen, Bt,
+                                (Bt + GNS_LANES - 1) / GNS_LANES, (hipStream_t)stream);
+}
+
 extern "C" int gns_forward(const gns_config* cfg, const void* topo_dev, const float* params, const float* buses,
-                           const float* lines, const float* generators, int64_t Bt, float* v, float* theta,
+                           const float* lines, const float* generators, int64_t Bt, const void* packed_inputs, float* v, float* theta,
                            float* total_loss, float* last_loss, void* workspace, size_t workspace_bytes, int save_state,
                            void* stream) {
   int rc = check_cfg(cfg);
@@ -255,8 +275,11 @@ extern "C" int gns_forward(const gns_config* cfg, const void* topo_dev, const fl
       return rc;
     }
   }
-  rc = gns_launch_pack_inputs((const int*)topo_dev, buses, lines, generators, pin, N, E, Gn, Bt, L.groups, st);
-  if (rc != GNS_OK) return rc;
+  if (packed_inputs) pin = (float*)packed_inputs;                  // a resident batch packed once by gns_prepack: nothing to redo
+  else {
+    rc = gns_launch_pack_inputs((const int*)topo_dev, buses, lines, generators, pin, N, E, Gn, Bt, L.groups, st);
+    if (rc != GNS_OK) return rc;
+  }
   GnsFwdArgs A;
   std::memset(&A, 0, sizeof(A));
   A.topo = (const int*)topo_dev; A.pt = pt; A.in = pin;
@@ -275,7 +298,7 @@ extern "C" int gns_forward(const gns_config* cfg, const void* topo_dev, const fl
 }
 
 extern "C" int gns_backward(const gns_config* cfg, const void* topo_dev, const float* params,
-                            const float* buses, const float* lines, const float* generators, int64_t Bt,
+                            const float* buses, const float* lines, const float* generators, int64_t Bt, const void* packed_inputs,
                             const void* fwd_workspace, size_t fwd_workspace_bytes, const float* grad_total,
                             const float* grad_last, const float* grad_v, const float* grad_theta, float* grad_params,
                             void* bwd_workspace, size_t bwd_workspace_bytes, void* stream) {
@@ -331,7 +354,8 @@ extern "C" int gns_backward(const gns_config* cfg, const void* topo_dev, const f
   GnsBwdArgs A;
   std::memset(&A, 0, sizeof(A));
   A.topo = (const int*)topo_dev;
-  A.pt = (const float*)(fw + L.off_pt); A.pn = (const float*)(fw + L.off_pn); A.in = (const float*)(fw + L.off_in);
+  A.pt = (const float*)(fw + L.off_pt); A.pn = (const float*)(fw + L.off_pn);
+  A.in = packed_inputs ? (const float*)packed_inputs : (const float*)(fw + L.off_in);
   A.state = (const float*)(fw + L.off_state); A.lam = (const float*)(fw + L.off_lam); A.msg = (const float*)(fw + L.off_msg);
   A.g_total = grad_total; A.g_last = grad_last; A.g_v = grad_v; A.g_theta = grad_theta;
   A.adj = (float*)(bw + B.off_adj); A.slots = (float*)(bw + B.off_slots); A.slab = (float*)(bw + B.off_slab);

@@ -97,14 +97,17 @@ class _GNSFunction(torch.autograd.Function):
         flat = mod._exec_flat(dev)                       # the parameters themselves, or their device mirror for a CPU-resident model
         with torch.cuda.device(dev):                     # the launch must land on the tensors' device, whatever the current device is
             stream = torch.cuda.current_stream(dev).cuda_stream
+            packed = mod._packed_inputs(lib, cfg, topo, buses, lines, gens, stream)
             _check(lib.gns_forward(ctypes.byref(cfg), topo.blob.data_ptr(), flat.data_ptr(), buses.data_ptr(), lines.data_ptr(),
-                                   gens.data_ptr(), Bt, v.data_ptr(), theta.data_ptr(), total.data_ptr(), last.data_ptr(),
+                                   gens.data_ptr(), Bt, None if packed is None else packed.data_ptr(),
+                                   v.data_ptr(), theta.data_ptr(), total.data_ptr(), last.data_ptr(),
                                    ws.data_ptr(), ws.numel(), int(need_grad), stream), 'gns_forward')
         if need_grad:
             ctx.cfg, ctx.topo, ctx.ws, ctx.flat, ctx.Bt, ctx.bwd_bytes = cfg, topo, ws, flat, Bt, bwd_b.value
             ctx.params = params
             ctx.param_versions = tuple(p._version for p in params)
             ctx.inputs = (buses, lines, gens)          # the backward of the grid-per-workgroup mapping re-reads them
+            ctx.packed = packed
             ctx.shapes = [p.shape for p in params]
         return v, theta, total, last
 
@@ -128,7 +131,7 @@ class _GNSFunction(torch.autograd.Function):
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             _check(lib.gns_backward(ctypes.byref(ctx.cfg), ctx.topo.blob.data_ptr(), flat.data_ptr(), bu.data_ptr(), li_.data_ptr(),
-                                    ge.data_ptr(), ctx.Bt, ctx.ws.data_ptr(),
+                                    ge.data_ptr(), ctx.Bt, None if ctx.packed is None else ctx.packed.data_ptr(), ctx.ws.data_ptr(),
                                     ctx.ws.numel(), ptr(keep[0]), ptr(keep[1]), ptr(keep[2]), ptr(keep[3]), grad.data_ptr(),
                                     bws.data_ptr(), bws.numel(), stream), 'gns_backward')
         pdev = ctx.params[0].device
@@ -184,6 +187,10 @@ class GNS(nn.Module):
         # the whole batch is compared when a case is first seen.  'always': whole batch on every call.  'first': never again.
         self.topology_check = 'grid0'
         self.__dict__['_mirror'] = None
+        # True: a batch that is passed again unchanged (same tensors, same versions) is brought into the kernels' input
+        # layout once instead of on every call (gns_prepack).  Off by default: the cache keeps the last batch alive.
+        self.cache_packed_inputs = False
+        self.__dict__['_pack_cache'] = None
 
     # ---- flat parameter storage -------------------------------------------------------------------
     def _config(self, n_bus, n_line, n_gen):
@@ -227,6 +234,22 @@ class GNS(nn.Module):
             self.__dict__['_mirror'] = mir
         mir.copy_(flat, non_blocking=False)
         return mir
+
+    def _packed_inputs(self, lib, cfg, topo, buses, lines, gens, stream):
+        if not self.cache_packed_inputs:
+            return None
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (buses, lines, gens)) + (id(topo),)
+        ent = self._pack_cache
+        if ent is not None and ent[0] == key:
+            return ent[2]
+        nbytes = ctypes.c_size_t()
+        _check(lib.gns_prepack_bytes(ctypes.byref(cfg), buses.shape[0], ctypes.byref(nbytes)), 'gns_prepack_bytes')
+        packed = torch.empty(nbytes.value, dtype=torch.uint8, device=buses.device)
+        _check(lib.gns_prepack(ctypes.byref(cfg), topo.blob.data_ptr(), buses.data_ptr(), lines.data_ptr(), gens.data_ptr(),
+                               buses.shape[0], packed.data_ptr(), packed.numel(), stream), 'gns_prepack')
+        # the entry holds the tensors themselves: their storage cannot be freed and handed to other data while it is cached
+        self.__dict__['_pack_cache'] = (key, (buses, lines, gens, topo), packed)
+        return packed
 
     def flat_parameters(self):
         """The flat fp32 parameter buffer (state_dict order); parameters are views into it."""

@@ -296,6 +296,35 @@ def test_reference_run_configurations_pinned_by_goldens(name, mapping, capsys):
         print(f'\n[{name} | {mapping}] error vs the REFERENCE\'s fp32 outputs: ' + '; '.join(report))
 
 
+def test_resident_batch_is_packed_once_and_repacked_when_it_changes():
+    """cache_packed_inputs: the same tensors passed again are not re-packed (gns_prepack); results are the same bits as with
+    per-call packing, and an in-place change of the inputs (version counter) invalidates the cached layout."""
+    import opf_graph_neural_solver_amd as amd
+    torch.manual_seed(0)
+    m = amd.GNS(20, 10, 3, 0.9, True).cuda()
+    bu, li, ge = amd.synth.synth_grids(118, 300, seed=4, device='cuda')
+
+    def run():
+        m.zero_grad()
+        out = m(bu, li, ge)
+        out[2].mean().backward()
+        return [o.detach().clone() for o in out] + [torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()]
+
+    base = run()
+    m.cache_packed_inputs = True
+    first, again = run(), run()
+    assert m._pack_cache is not None
+    for a, b, c in zip(base, first, again):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    bu[:, :, 2] *= 1.01                                          # in place: same storage, new version
+    changed = run()
+    m.cache_packed_inputs = False
+    fresh = run()
+    assert not torch.equal(changed[2], base[2])
+    for a, b in zip(changed, fresh):
+        assert torch.equal(a, b)
+
+
 def test_in_place_parameter_update_between_forward_and_backward_raises():
     """forward / optimizer.step() (or any in-place parameter write) / backward mixes weights packed by the forward with the
     live buffer; torch autograd raises in that situation and so must the fused path."""
