@@ -16,14 +16,16 @@ struct GnsTuning {
   int dw_mfma;       // GNS_DW_MFMA=0: packed-FMA weight-gradient engine instead of the matrix pipe
   int gw_ready;      // gns_gw_init_device() succeeded
   int train_mapping; // GNS_TRAIN_MAPPING: mapping of the training-mode forward + backward pair: 0 auto, 1 lane, 2 lds
+  int bwd_variant;   // GNS_BWD_VARIANT: family sweep of the lane-per-grid backward: 1 wide half-wave records, 2 layer-wise + sub-record windows
 };
 GnsTuning make_tuning() {
-  GnsTuning t{0, 0, GNS_FWD_THREADS / 64, 1, 1, 0, 0};
+  GnsTuning t{0, 0, GNS_FWD_THREADS / 64, 1, 1, 0, 0, 2};
   if (const char* e = std::getenv("GNS_FWD_MAPPING")) t.fwd_mapping = !std::strcmp(e, "lane") ? 1 : (!std::strcmp(e, "lds") ? 2 : 0);
   if (const char* e = std::getenv("GNS_GW_PACK")) { const int p = std::atoi(e); if (p >= 1 && p <= 16) t.gw_pack = p; }
   if (const char* e = std::getenv("GNS_FWD_WAVES")) { const int w = std::atoi(e); if (gns_part_index(w) >= 0 && w * 64 <= GNS_FWD_MAX_THREADS) t.fwd_waves = w; }
   if (const char* e = std::getenv("GNS_FWD_PLANE")) t.fwd_plane = e[0] == '0' ? 0 : 1;
   if (const char* e = std::getenv("GNS_DW_MFMA")) t.dw_mfma = e[0] == '0' ? 0 : 1;
+  if (const char* e = std::getenv("GNS_BWD_VARIANT")) { const int v = std::atoi(e); if (v == 1 || v == 2) t.bwd_variant = v; }
   if (const char* e = std::getenv("GNS_TRAIN_MAPPING")) t.train_mapping = !std::strcmp(e, "lane") ? 1 : (!std::strcmp(e, "lds") ? 2 : 0);
   t.gw_ready = (gns_gw_init_device() == GNS_OK && gns_gw_backward_init_device() == GNS_OK) ? 1 : 0;
   return t;
@@ -39,6 +41,7 @@ extern "C" int gns_set_option(const char* name, int value) {
   if (!name) return GNS_EINVAL;
   GnsTuning& t = tuning();
   if (!std::strcmp(name, "fwd_mapping")) { if (value < 0 || value > 2) return GNS_EINVAL; t.fwd_mapping = value; return GNS_OK; }
+  if (!std::strcmp(name, "bwd_variant")) { if (value < 1 || value > 2) return GNS_EINVAL; t.bwd_variant = value; return GNS_OK; }
   if (!std::strcmp(name, "train_mapping")) { if (value < 0 || value > 2) return GNS_EINVAL; t.train_mapping = value; return GNS_OK; }
   if (!std::strcmp(name, "gw_pack")) { if (value < 0 || value > 16) return GNS_EINVAL; t.gw_pack = value; return GNS_OK; }
   if (!std::strcmp(name, "fwd_waves")) { if (gns_part_index(value) < 0 || value * 64 > GNS_FWD_MAX_THREADS) return GNS_EINVAL; t.fwd_waves = value; return GNS_OK; }
@@ -51,6 +54,7 @@ extern "C" int gns_get_option(const char* name, int* value) {
   const GnsTuning& t = tuning();
   if (!std::strcmp(name, "fwd_mapping")) *value = t.fwd_mapping;
   else if (!std::strcmp(name, "train_mapping")) *value = t.train_mapping;
+  else if (!std::strcmp(name, "bwd_variant")) *value = t.bwd_variant;
   else if (!std::strcmp(name, "gw_pack")) *value = t.gw_pack;
   else if (!std::strcmp(name, "fwd_waves")) *value = t.fwd_waves;
   else if (!std::strcmp(name, "fwd_plane")) *value = t.fwd_plane;
@@ -369,7 +373,7 @@ extern "C" int gns_backward(const gns_config* cfg, const void* topo_dev, const f
   prof_mark(1, true, st);
   // The weight-gradient contraction over the grids runs on the matrix pipe (exact fp32) unless GNS_DW_MFMA=0 asks for
   // the packed-FMA register tiles; both are parity-tested (gns_backward.hip, "weight-gradient engines").
-  rc = gns_launch_backward(d, h, cfg->multiple_phi, tuning().dw_mfma, A, blocks, st);
+  rc = gns_launch_backward(d, h, cfg->multiple_phi, tuning().dw_mfma, tuning().bwd_variant, A, blocks, st);
   prof_mark(1, false, st);
   if (rc != GNS_OK) return rc;
   return gns_launch_reduce(A.slab, (float*)(bw + B.off_part), (float*)(bw + B.off_tmp), params, grad_params, nslab, B.slab_floats,

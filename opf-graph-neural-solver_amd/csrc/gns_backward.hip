@@ -19,7 +19,12 @@
 
 
 // ------------------------------------------------------------------------------------------------
-template <int D, int H, bool MULTI, bool MFMA>
+// V2 (three phi nets, matrix-pipe engine): the family sweep runs the layer-wise data path - each layer's weight gradient is
+// contracted through a 7 KB sub-record window as soon as its operands exist (half the LDS stores of the wide half-wave
+// records), the input adjoints stream out four at a time into their consumers (no 36-register adjoint array), phi' is
+// recomputed as head (once per bus) + tail (per line), and the latent columns of phi's dW1 and d/dm are taken once per bus
+// on the sum of the lines' first-layer adjoints (phi's first layer is linear in m(dst)).
+template <int D, int H, bool MULTI, bool MFMA, bool V2>
 __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArgs A) {
   using C = GnsDims<D, H, MULTI>;
   constexpr int RB = C::RB;
@@ -41,8 +46,9 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
   const long long R = gns_in_rows(N, E);
   const float* IN = A.in;
 
-  constexpr int RECF = gns_cmax(GNS_REC_ROWS * gns_cmax(RecLay<C::LF_IN, H, D>::RS, RecLay<C::LF_IN, H, 1>::RS),
-                                2 * GNS_REC_ROWS * RecLay2<C::PHI_IN, H>::RS) + 32;   // +32: the MFMA variant reads 16-wide column blocks
+  constexpr int RECF = V2 ? GwSub::RECF
+                          : gns_cmax(GNS_REC_ROWS * gns_cmax(RecLay<C::LF_IN, H, D>::RS, RecLay<C::LF_IN, H, 1>::RS),
+                                     2 * GNS_REC_ROWS * RecLay2<C::PHI_IN, H>::RS) + 32;   // +32: the MFMA variant reads 16-wide column blocks
   __shared__ __attribute__((aligned(16))) float rec_all[W][RECF];
   __shared__ float red[2][W][GNS_LANES];
   float* rec = rec_all[wave];
@@ -260,6 +266,144 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
         for (int i = 0; i < D / 2; ++i) x[i] = m[i];
         x[D / 2] = f2{ea.x, ea.y}; x[D / 2 + 1] = f2{ea.z, ea.w}; x[D / 2 + 2] = f2{eb.x, 0.f};
       };
+      if constexpr (V2) {
+      static_for<0, 3>([&](auto o_) {
+        constexpr int l = (decltype(o_)::value == 0) ? 2 : decltype(o_)::value - 1;   // L_m first: its upstream is mbar_{k+1} itself
+        constexpr int fphi = l == 0 ? 1 : (l == 1 ? 0 : 2);
+        constexpr int OUT = (l == 2) ? D : 1, OUTP = OUT + (OUT & 1);
+        constexpr int LIN = C::LF_IN, XL = (LIN + 1) / 2, PIN = C::PHI_IN, SOFF = 2 + D / 2;
+        constexpr int NB1 = (2 * XL + 15) / 16, NA4 = (OUTP + 11) / 12, NDM = (D + 15) / 16;
+        using NL = NLay<LIN, H, OUTP>;
+        if (l == 2 && k == K - 1) return;
+        cfp nb = PN + A.n_off[C::NPHI + l] + koff * A.n_sz[C::NPHI + l];
+        cfp pnb = PN + A.n_off[fphi] + koff * A.n_sz[fphi];
+        cfp ptb = PT + A.t_off[fphi] + koff * A.t_sz[fphi];
+        f32x4 T1[NB1], T2, T4[NA4], TP1, TP2, TPm[NDM];
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NB1; ++t) T1[t] = z4;
+#pragma unroll
+        for (int t = 0; t < NA4; ++t) T4[t] = z4;
+#pragma unroll
+        for (int t = 0; t < NDM; ++t) TPm[t] = z4;
+        T2 = z4; TP1 = z4; TP2 = z4;
+        for (int n = n0; n < n1; ++n) {
+          const long long ar = adj_row(n), rr = state_row(k, n);
+          const f4 a0 = *row_ptr(A.adj, ar, lane);
+          f4 xsum = *row_ptr(A.adj, ar + 1, lane);            // d/dv, d/dtheta, d/ddp of the L inputs so far
+          const f4 s0 = *row_ptr(A.state, rr, lane);
+          f2 xs[XL];                                          // [v theta | dp dq | m | sum_e h_e | deg, 1]
+          f2 (&m)[D / 2] = reinterpret_cast<f2 (&)[D / 2]>(xs[2]);
+          f2 (&S)[H / 2] = reinterpret_cast<f2 (&)[H / 2]>(xs[SOFF]);
+          load_pairs<D>(A.state, rr + 1, lane, m);
+          f2 macc[D / 2];                                     // d/dm_{k+1} (identity path main.py:188), keeps accumulating
+          load_pairs<D>(A.adj, ar + RM, lane, macc);
+          load_pairs<H>(A.msg, ((((long long)k * A.G + g) * N + n) * C::NPHI + fphi) * C::HQ, lane, S);
+          const int p0 = in_ptr[n], p1 = in_ptr[n + 1];
+          xs[0] = f2{s0.x, s0.y}; xs[1] = f2{s0.z, s0.w};
+          xs[XL - 1] = f2{(float)(p1 - p0), 1.f};             // deg, and the 1 whose column of dW1 is db1
+          f2 gS[H / 2];                                       // adjoint of the hidden-vector sum: what every line ending at n receives
+          {
+            f2 a1[H / 2], a2[H / 2], g2[H / 2], g1[H / 2];
+            mlp2_fwd<LIN, H>(PT + A.t_off[C::NPHI + l] + koff * A.t_sz[C::NPHI + l], xs, a1, a2);
+            // output layer: g2 = (W4^T g3) * lrelu'(a2);  dW4 | db4 += g3 (x) [a2 | 1]
+            if constexpr (l == 2) {
+              bwd_rows<OUTP, H>(nb, macc, g2);                                          // m += L_m (main.py:188)
+            } else {
+              const f2 g3s[1] = {f2{l == 0 ? a0.y : (is_gen[n] ? 0.f : a0.x), 0.f}};   // theta += L_theta (:182); v only without a generator (:184-186)
+              bwd_rows<2, H>(nb, g3s, g2);
+            }
+#pragma unroll
+            for (int u = 0; u < H / 2; ++u) g2[u] = g2[u] * dlrelu2(a2[u]);
+            static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putB(rec, lane, j, a2[j]); });
+            gws_putB(rec, lane, H / 2, f2{1.f, 0.f});
+            static_for<0, NA4>([&](auto t_) {
+              constexpr int t = decltype(t_)::value;
+              if constexpr (l == 2) {
+                static_for<0, 6>([&](auto j_) { constexpr int j = decltype(j_)::value; if constexpr (6 * t + j < D / 2) gws_putA(rec, lane, j, macc[6 * t + j]); });
+              } else {
+                gws_putA(rec, lane, 0, f2{l == 0 ? a0.y : (is_gen[n] ? 0.f : a0.x), 0.f});
+              }
+              gws_w2r(); gws_pass(rec, lane, T4[t]); gws_r2w();
+            });
+            // hidden layer: g1 = (W2^T g2) * lrelu'(a1);  dW2 | db2 += g2 (x) [a1 | 1]
+            bwd_rows<H, H>(nb + NL::oW2, g2, g1);
+#pragma unroll
+            for (int u = 0; u < H / 2; ++u) g1[u] = g1[u] * dlrelu2(a1[u]);
+            static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA(rec, lane, j, g2[j]); gws_putB(rec, lane, j, a1[j]); });
+            gws_putB(rec, lane, H / 2, f2{1.f, 0.f});
+            gws_w2r(); gws_pass(rec, lane, T2); gws_r2w();
+            // first layer: dW1 | db1 += g1 (x) [x | 1] in 16-column windows
+            static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA(rec, lane, j, g1[j]); });
+            static_for<0, NB1>([&](auto t_) {
+              constexpr int t = decltype(t_)::value;
+              static_for<0, 8>([&](auto j_) { constexpr int j = decltype(j_)::value; if constexpr (8 * t + j < XL) gws_putB(rec, lane, j, xs[8 * t + j]); });
+              gws_w2r(); gws_pass(rec, lane, T1[t]); gws_r2w();
+            });
+            // input adjoints, four at a time, straight to their consumers
+            bwd_inputs<(LIN + 3) / 4, H>(nb + NL::total, g1, [&](auto ip_, f2 v) {
+              constexpr int ip = decltype(ip_)::value;
+              if constexpr (ip == 0) { xsum.x += v.x; xsum.y += v.y; }
+              else if constexpr (ip == 1) xsum.z += v.x;
+              else if constexpr (ip < SOFF) macc[ip - 2] += v;
+              else if constexpr (ip < SOFF + H / 2) gS[ip - SOFF] = v;
+            });
+          }
+          if (p0 < p1) {                                      // back through the hidden vectors of the lines ending at n
+            f2 uh[H / 2], G1[H / 2];
+            phi_head<D, H>(ptb, m, uh);
+#pragma unroll
+            for (int j = 0; j < H / 2; ++j) G1[j] = f2{0.f, 0.f};
+            for (int p = p0; p < p1; ++p) {
+              const f4 ea = *row_ptr(IN, row_ein + 3LL * p, lane), eb = *row_ptr(IN, row_ein + 3LL * p + 1, lane);
+              const f2 xt[3] = {f2{ea.x, ea.y}, f2{ea.z, ea.w}, f2{eb.x, 0.f}};
+              f2 a1[H / 2], a2[H / 2], g2[H / 2], g1[H / 2];
+              phi_tail<PIN, H, D>(ptb, uh, xt, a1, a2);
+#pragma unroll
+              for (int u = 0; u < H / 2; ++u) g2[u] = gS[u] * dlrelu2(a2[u]);
+              bwd_rows<H, H>(pnb, g2, g1);
+#pragma unroll
+              for (int u = 0; u < H / 2; ++u) { g1[u] = g1[u] * dlrelu2(a1[u]); G1[u] += g1[u]; }
+              static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA(rec, lane, j, g1[j]); });
+              gws_putB(rec, lane, 0, xt[0]); gws_putB(rec, lane, 1, xt[1]); gws_putB(rec, lane, 2, f2{xt[2].x, 1.f});
+              gws_w2r(); gws_pass(rec, lane, TP1); gws_r2w();
+              static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA(rec, lane, j, g2[j]); gws_putB(rec, lane, j, a1[j]); });
+              gws_putB(rec, lane, H / 2, f2{1.f, 0.f});
+              gws_w2r(); gws_pass(rec, lane, TP2); gws_r2w();
+            }
+            // x = [m(dst) | ...] (main.py:155): d/dm += W1[:, :d]^T G1 and the latent columns of dW1 += G1 (x) m, once per bus
+            bwd_inputs<(D + 3) / 4, H>(pnb + NLay2<PIN, H>::total, G1, [&](auto ip_, f2 v) {
+              constexpr int ip = decltype(ip_)::value;
+              if constexpr (ip < D / 2) macc[ip] += v;
+            });
+            static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA(rec, lane, j, G1[j]); });
+            static_for<0, NDM>([&](auto t_) {
+              constexpr int t = decltype(t_)::value;
+              static_for<0, 8>([&](auto j_) { constexpr int j = decltype(j_)::value; if constexpr (8 * t + j < D / 2) gws_putB(rec, lane, j, m[8 * t + j]); });
+              gws_w2r(); gws_pass(rec, lane, TPm[t]); gws_r2w();
+            });
+          }
+          *row_ptr(A.adj, ar + 1, lane) = xsum;
+          store_pairs<D>(A.adj, ar + RM, lane, macc);
+        }
+        {   // flush the family's tiles into the wave's slab (folded blocks: W1[H][IN] b1 W2 b2 [W4 b4])
+          constexpr int ob1 = LIN * H, oW2 = ob1 + H, ob2 = oW2 + H * H, oW4 = ob2 + H, ob4 = oW4 + OUT * H;
+          float* lb_ = slab + A.g_off[C::NPHI + l] + koff * A.g_sz[C::NPHI + l];
+          static_for<0, NB1>([&](auto t_) { constexpr int t = decltype(t_)::value;
+            gws_flush(lane, T1[t], lb_, [&](int c, int il) { const int i = 16 * t + il; return c < H ? (i < LIN ? c * LIN + i : (i == LIN ? ob1 + c : -1)) : -1; }); });
+          gws_flush(lane, T2, lb_, [&](int c, int il) { return c < H ? (il < H ? oW2 + c * H + il : (il == H ? ob2 + c : -1)) : -1; });
+          static_for<0, NA4>([&](auto t_) { constexpr int t = decltype(t_)::value;
+            gws_flush(lane, T4[t], lb_, [&](int c, int il) { const int j = 12 * t + c; return (c < 12 && j < OUT) ? (il < H ? oW4 + j * H + il : (il == H ? ob4 + j : -1)) : -1; }); });
+          constexpr int pb1 = PIN * H, pW2 = pb1 + H, pb2 = pW2 + H * H;
+          float* pb_ = slab + A.g_off[fphi] + koff * A.g_sz[fphi];
+          gws_flush(lane, TP1, pb_, [&](int c, int il) { return c < H ? (il < PIN - D ? c * PIN + D + il : (il == PIN - D ? pb1 + c : -1)) : -1; });
+          gws_flush(lane, TP2, pb_, [&](int c, int il) { return c < H ? (il < H ? pW2 + c * H + il : (il == H ? pb2 + c : -1)) : -1; });
+          static_for<0, NDM>([&](auto t_) { constexpr int t = decltype(t_)::value;
+            gws_flush(lane, TPm[t], pb_, [&](int c, int il) { const int i = 16 * t + il; return (c < H && i < D) ? c * PIN + i : -1; }); });
+        }
+        STAMP(5 + l)
+      });
+      } else {
       static_for<0, 3>([&](auto o_) {
         constexpr int l = (decltype(o_)::value == 0) ? 2 : decltype(o_)::value - 1;   // L_m first: its upstream is mbar_{k+1} itself
         constexpr int fphi = MULTI ? (l == 0 ? 1 : (l == 1 ? 0 : 2)) : 0;
@@ -359,6 +503,7 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
         }
         engP.flush(lane, slab + A.g_off[0] + koff * A.g_sz[0]);
       }
+      }   // !V2
       STAMP(8)
     }
     __syncthreads();
@@ -435,17 +580,18 @@ __global__ void gns_unfold_kernel(const float* __restrict__ gf, const float* __r
   for (int e = threadIdx.x; e < rest; e += blockDim.x) dst[H * IN + e] += g[H * INF + e];
 }
 
-template <int D, int H, bool MULTI, bool MFMA>
+template <int D, int H, bool MULTI, bool MFMA, bool V2>
 static int launch_backward_t(const GnsBwdArgs& A, int blocks, hipStream_t st) {
-  hipLaunchKernelGGL((gns_backward_kernel<D, H, MULTI, MFMA>), dim3(blocks), dim3(GNS_BWD_THREADS), 0, st, A);
+  hipLaunchKernelGGL((gns_backward_kernel<D, H, MULTI, MFMA, V2>), dim3(blocks), dim3(GNS_BWD_THREADS), 0, st, A);
   return hipGetLastError() == hipSuccess ? GNS_OK : GNS_ELAUNCH;
 }
 
-int gns_launch_backward(int d, int h, int multi, int mfma, const GnsBwdArgs& A, int blocks, hipStream_t st) {
+int gns_launch_backward(int d, int h, int multi, int mfma, int variant, const GnsBwdArgs& A, int blocks, hipStream_t st) {
 #define GNS_CASE(DD, HH)                                                                                      \
   if (d == DD && h == HH) {                                                                                   \
-    if (mfma) return multi ? launch_backward_t<DD, HH, true, true>(A, blocks, st) : launch_backward_t<DD, HH, false, true>(A, blocks, st);   \
-    return multi ? launch_backward_t<DD, HH, true, false>(A, blocks, st) : launch_backward_t<DD, HH, false, false>(A, blocks, st);          \
+    if (mfma && multi && variant == 2) return launch_backward_t<DD, HH, true, true, true>(A, blocks, st);     \
+    if (mfma) return multi ? launch_backward_t<DD, HH, true, true, false>(A, blocks, st) : launch_backward_t<DD, HH, false, true, false>(A, blocks, st);   \
+    return multi ? launch_backward_t<DD, HH, true, false, false>(A, blocks, st) : launch_backward_t<DD, HH, false, false, false>(A, blocks, st);          \
   }
   GNS_FOR_EACH_DIMS(GNS_CASE)
 #undef GNS_CASE

@@ -52,32 +52,6 @@ __device__ __forceinline__ void gb_write_row(float* row, const f2 (&src)[NF / 2]
   for (int i = 0; i < NF / 2; ++i) reinterpret_cast<f2*>(row)[i] = src[i];
 }
 
-// gout[i] = sum_j Wn[j][i] gin[j] from an [NJ][H] stream (output layer and hidden layer of the data path)
-template <int NJP, int H>
-__device__ __forceinline__ void bwd_rows(cfp blk, const f2 (&gin)[NJP / 2], f2 (&gout)[H / 2]) {
-  stream_pairs<NJP * H>(blk, [&](auto w_, f2 s) {
-    constexpr int w = decltype(w_)::value, j = w / H, i = (w % H) / 2;
-    const f2 gj = splat(lane_of<j>(gin));
-    gout[i] = (j == 0) ? s * gj : __builtin_elementwise_fma(s, gj, gout[i]);
-  });
-  pin_all(gout);
-}
-// Input adjoints from the input-major stream W1x[NG][H][4]: four inputs at a time, each finished pair handed to sink(ic<pair>, value)
-template <int NG, int H, class F>
-__device__ __forceinline__ void bwd_inputs(cfp blk, const f2 (&g1)[H / 2], F&& sink) {
-  f2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
-  stream_pairs<NG * H * 4>(blk, [&](auto w_, f2 s) {
-    constexpr int w = decltype(w_)::value, g = w / (4 * H), r = w % (4 * H), j = r / 4, half = (r % 4) / 2;
-    const f2 gj = splat(lane_of<j>(g1));
-    if constexpr (half == 0) acc0 = (j == 0) ? s * gj : __builtin_elementwise_fma(s, gj, acc0);
-    else acc1 = (j == 0) ? s * gj : __builtin_elementwise_fma(s, gj, acc1);
-    if constexpr (j == H - 1 && half == 1) {
-      pin(acc0); pin(acc1);
-      sink(std::integral_constant<int, 2 * g>{}, acc0);
-      sink(std::integral_constant<int, 2 * g + 1>{}, acc1);
-    }
-  });
-}
 constexpr int gb_max(int a, int b) { return a > b ? a : b; }
 }  // namespace
 

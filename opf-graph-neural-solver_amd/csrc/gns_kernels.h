@@ -58,7 +58,7 @@ struct GnsBwdArgs {
   int N, E, K, part_idx;
 };
 
-int gns_launch_backward(int d, int h, int multi, int mfma, const GnsBwdArgs& A, int blocks, hipStream_t st);
+int gns_launch_backward(int d, int h, int multi, int mfma, int variant, const GnsBwdArgs& A, int blocks, hipStream_t st);
 int gns_launch_reduce(const float* slab, float* part, float* tmp, const float* flat, float* grad, long long nslab, long long sf,
                       const GnsFamilies& fam, int K, int D, int H, hipStream_t st);
 int gns_launch_forward(int d, int h, int multi, const GnsFwdArgs& A, int threads, hipStream_t st);

@@ -13,8 +13,8 @@ combos = sys.argv[4] if len(sys.argv) > 4 else '1,2:1,2:4'
 m = amd.GNS(20, 10, K, 0.9, True).cuda(); m.topology_check = 'first'
 bu, li, ge = amd.synth.synth_grids(case, bt, seed=1, device='cuda')
 for c in combos.split(','):
-    mapping, pack = (int(x) for x in (c.split(':') + ['0'])[:2])
-    amd.set_option('train_mapping', mapping); amd.set_option('gw_pack', pack)
+    mapping, pack, variant = (int(x) for x in (c.split(':') + ['0', '2'])[:3])
+    amd.set_option('train_mapping', mapping); amd.set_option('gw_pack', pack); amd.set_option('bwd_variant', variant)
     for it in range(2):
         out = m(bu, li, ge); out[2].mean().backward(); m.zero_grad()
     lib.gns_profile_enable(16)
@@ -26,4 +26,4 @@ for c in combos.split(','):
     lib.gns_profile_read(0, ctypes.byref(a), ctypes.byref(n)); f = a.value / max(n.value, 1)
     lib.gns_profile_read(1, ctypes.byref(a), ctypes.byref(n)); b = a.value / max(n.value, 1)
     lib.gns_profile_enable(0)
-    print(f"case{case} x {bt} K={K} train_mapping {mapping} pack {pack}: fwd(train) {f:.3f} ms   bwd {b:.3f} ms   fwd+bwd loop {(t1 - t0) / 10 * 1e3:.3f} ms", flush=True)
+    print(f"case{case} x {bt} K={K} train_mapping {mapping} pack {pack} bwd_variant {variant}: fwd(train) {f:.3f} ms   bwd {b:.3f} ms   fwd+bwd loop {(t1 - t0) / 10 * 1e3:.3f} ms", flush=True)
