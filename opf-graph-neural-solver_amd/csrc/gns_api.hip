@@ -94,13 +94,18 @@ void prof_mark(int which, bool start, hipStream_t st) {
 
 // Which mapping runs a training-mode forward and its backward.  Evaluated identically by gns_forward and gns_backward:
 // changing "train_mapping" / "gw_pack" between a forward and its backward is a caller error.
-static int gw_train_pack(const gns_config* c) {
+static int gw_train_pack(const gns_config* c, int64_t Bt) {
   const GnsTuning& T = tuning();
   const int P = T.gw_pack > 0 ? T.gw_pack : 1;
-  if (!T.gw_ready || T.train_mapping != 2) return 0;                 // auto = lane-per-grid until the on-chip pair is the faster one
+  if (!T.gw_ready || T.train_mapping == 1) return 0;
   if (!gns_gw_supported(c->n_bus, c->n_line, c->latent_dim, c->hidden_dim, c->multiple_phi, P)) return 0;
   if (!gns_gw_backward_supported(c->n_bus, c->n_line, c->latent_dim, c->hidden_dim, c->multiple_phi, P)) return 0;
-  return P;
+  if (T.train_mapping == 2) return P;
+  // auto: the lane-per-grid pair needs one workgroup per 64 grids and ~256 of them to fill the chip; below ~6000 grids per
+  // GPU the grid-per-workgroup pair (one workgroup per grid) is the faster one (measured, case118 x 4096: 1.99 vs 3.17 ms);
+  // above, the lane-per-grid backward wins (its weight streams are re-used across the buses of 64 grids).
+  const int64_t groups = (Bt + GNS_LANES - 1) / GNS_LANES;
+  return (groups <= 96 && gns_gw_backward_wpg(c->n_bus) <= 2) ? P : 0;
 }
 struct GwTrainLayout { size_t off_pt, off_pn, off_save; GwSaveLayout sv; size_t fwd_total; int blocks, waves; size_t off_slab, off_part, off_tmp, bwd_total; long long slab_floats, nslab; };
 static GwTrainLayout gw_train_layout(const gns_config* c, int64_t Bt, int P) {
@@ -176,7 +181,7 @@ extern "C" int gns_workspace_bytes(const gns_config* cfg, int64_t Bt, int save_s
   if (Bt <= 0) return GNS_EINVAL;
   GnsFwdLayout L;
   gns_fwd_layout(cfg->n_bus, cfg->n_line, cfg->latent_dim, cfg->hidden_dim, cfg->K, cfg->multiple_phi, Bt, save_state, &L);
-  const int P = save_state ? gw_train_pack(cfg) : 0;
+  const int P = save_state ? gw_train_pack(cfg, Bt) : 0;
   if (P > 0) {
     const GwTrainLayout G = gw_train_layout(cfg, Bt, P);
     if (fwd_bytes) *fwd_bytes = G.fwd_total;
@@ -226,7 +231,7 @@ extern "C" int gns_forward(const gns_config* cfg, const void* topo_dev, const fl
   hipStream_t st = (hipStream_t)stream;
   char* ws = (char*)workspace;
   const GnsTuning& T = tuning();
-  if (const int TP = save_state ? gw_train_pack(cfg) : 0) {          // training-mode forward of the grid-per-workgroup pair
+  if (const int TP = save_state ? gw_train_pack(cfg, Bt) : 0) {          // training-mode forward of the grid-per-workgroup pair
     const GwTrainLayout GL = gw_train_layout(cfg, Bt, TP);
     if (workspace_bytes < GL.fwd_total) return GNS_ESIZE;
     float* gpt = (float*)(ws + GL.off_pt);
@@ -311,7 +316,7 @@ extern "C" int gns_backward(const gns_config* cfg, const void* topo_dev, const f
   if (!topo_dev || !params || !fwd_workspace || !grad_params || !bwd_workspace || Bt <= 0) return GNS_EINVAL;
   if (!dims_supported(cfg->latent_dim, cfg->hidden_dim) || cfg->K > GNS_MAX_K) return GNS_EUNSUPPORTED;
   const int N = cfg->n_bus, E = cfg->n_line, K = cfg->K, d = cfg->latent_dim, h = cfg->hidden_dim;
-  if (const int TP = gw_train_pack(cfg)) {                            // the pair of the grid-per-workgroup training forward
+  if (const int TP = gw_train_pack(cfg, Bt)) {                            // the pair of the grid-per-workgroup training forward
     if (!buses || !lines || !generators) return GNS_EINVAL;
     const GwTrainLayout GL = gw_train_layout(cfg, Bt, TP);
     if (fwd_workspace_bytes < GL.fwd_total || bwd_workspace_bytes < GL.bwd_total) return GNS_ESIZE;

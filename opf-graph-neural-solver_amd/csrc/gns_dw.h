@@ -540,10 +540,19 @@ struct GwSub {
 };
 __device__ __forceinline__ void gws_w2r() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 __device__ __forceinline__ void gws_r2w() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+#ifdef GNS_ABLATE_REC
+__device__ __forceinline__ void gws_putA(float* rec, int lane, int pair, f2 v) { asm volatile("" :: "v"(v)); }
+__device__ __forceinline__ void gws_putB(float* rec, int lane, int pair, f2 v) { asm volatile("" :: "v"(v)); }
+#else
 __device__ __forceinline__ void gws_putA(float* rec, int lane, int pair, f2 v) { reinterpret_cast<f2*>(rec + lane * GwSub::RS)[pair] = v; }
 __device__ __forceinline__ void gws_putB(float* rec, int lane, int pair, f2 v) { reinterpret_cast<f2*>(rec + lane * GwSub::RS + GwSub::NA)[pair] = v; }
+#endif
 // One contraction pass over the window, in two halves of 8 k-steps (16 operand registers in flight instead of 32)
 __device__ __forceinline__ void gws_pass(const float* rec, int lane, f32x4& Dt) {
+#ifdef GNS_ABLATE_PASS
+  asm volatile("" : "+v"(Dt));
+  return;
+#endif
   const float* base = rec + (((lane >> 5) & 1) + 4 * ((lane >> 4) & 1)) * GwSub::RS + (lane & 15);
   static_for<0, 2>([&](auto h_) {
     constexpr int hh = decltype(h_)::value;

@@ -69,11 +69,12 @@ def dw_engine(request):
     """The weight-gradient paths of the lane-per-grid backward kernel (gns_set_option "dw_mfma", "bwd_variant"): matrix pipe
     with the layer-wise sweep and sub-record windows (default), matrix pipe with wide half-wave records, packed-FMA tiles."""
     import opf_graph_neural_solver_amd as amd
-    old = amd.get_option('dw_mfma'), amd.get_option('bwd_variant')
+    old = amd.get_option('dw_mfma'), amd.get_option('bwd_variant'), amd.get_option('train_mapping')
+    amd.set_option('train_mapping', 1)                 # (small batches would otherwise go to the grid-per-workgroup pair)
     amd.set_option('dw_mfma', 0 if request.param == 'packed-fma' else 1)
     amd.set_option('bwd_variant', 1 if request.param == 'matrix-pipe-wide-records' else 2)
     yield request.param
-    amd.set_option('dw_mfma', old[0]); amd.set_option('bwd_variant', old[1])
+    amd.set_option('dw_mfma', old[0]); amd.set_option('bwd_variant', old[1]); amd.set_option('train_mapping', old[2])
 
 
 @pytest.mark.parametrize('name', shallow_golden_names())
@@ -183,6 +184,8 @@ def test_weight_gradient_engines_agree_on_large_batches(case, bt, d, multi, K):
     bu, li, ge = amd.synth.synth_grids(case, bt, seed=5, device='cuda')
     grads = []
     old = amd.get_option('dw_mfma')
+    old_map = amd.get_option('train_mapping')
+    amd.set_option('train_mapping', 1)
     for flag in (1, 0):
         amd.set_option('dw_mfma', flag)
         torch.manual_seed(0)
@@ -190,13 +193,25 @@ def test_weight_gradient_engines_agree_on_large_batches(case, bt, d, multi, K):
         m(bu, li, ge)[2].mean().backward()
         grads.append(torch.cat([p.grad.reshape(-1) for p in m.parameters()]).double().cpu())
     amd.set_option('dw_mfma', old)
+    amd.set_option('train_mapping', old_map)
     scale = float(grads[1].abs().max())
     assert scale > 0
     assert float((grads[0] - grads[1]).abs().max()) <= 1e-6 * scale
 
 
-def test_full_size_batch_against_oracle_sample_and_properties():
-    """BASELINE config 2/3 scale: case30 batch 4096 and case118 batch 16384 through the fused path.
+@pytest.fixture(params=['lane-per-grid', 'grid-per-workgroup'])
+def train_mapping(request):
+    """Pin the training-mode kernels (the default picks per batch size: gns_api.hip, gw_train_pack)."""
+    import opf_graph_neural_solver_amd as amd
+    old = amd.get_option('train_mapping')
+    amd.set_option('train_mapping', 1 if request.param == 'lane-per-grid' else 2)
+    yield request.param
+    amd.set_option('train_mapping', old)
+
+
+def test_full_size_batch_against_oracle_sample_and_properties(train_mapping):
+    """BASELINE config 2/3 scale: case30 batch 4096 and case118 batch 16384 through the fused path, under either
+    training mapping.
     Checked (a) against the CPU oracle on a sample of grids, (b) bitwise run-to-run reproducibility,
     (c) batch-composition independence: a grid's outputs do not depend on its neighbours in the batch,
     (d) the batch gradient is the mean of shard gradients (the identity data parallelism relies on)."""
@@ -501,7 +516,12 @@ def test_evaluation_mode_saves_nothing_and_matches_training_mode():
     torch.cuda.synchronize(); peak_eval = torch.cuda.max_memory_allocated() - base
     assert not ev[2].requires_grad
     torch.cuda.reset_peak_memory_stats()
-    tr = m(bu, li, ge)
+    old_train = amd.get_option('train_mapping')
+    amd.set_option('train_mapping', 1)
+    try:
+        tr = m(bu, li, ge)
+    finally:
+        amd.set_option('train_mapping', old_train)
     torch.cuda.synchronize(); peak_train = torch.cuda.max_memory_allocated() - base
     assert tr[2].requires_grad
     for a, b in zip(ev, tr):

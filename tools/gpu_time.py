@@ -13,7 +13,7 @@ combos = sys.argv[4] if len(sys.argv) > 4 else '1,2:1,2:4'
 m = amd.GNS(20, 10, K, 0.9, True).cuda(); m.topology_check = 'first'
 bu, li, ge = amd.synth.synth_grids(case, bt, seed=1, device='cuda')
 for c in combos.split(','):
-    mapping, pack, variant = (int(x) for x in (c.split(':') + ['0', '2'])[:3])
+    mapping, pack, variant = (int(x) for x in (c.split(':') + ['0', '2'][len(c.split(':')) - 1:])[:3])
     amd.set_option('train_mapping', mapping); amd.set_option('gw_pack', pack); amd.set_option('bwd_variant', variant)
     for it in range(2):
         out = m(bu, li, ge); out[2].mean().backward(); m.zero_grad()
