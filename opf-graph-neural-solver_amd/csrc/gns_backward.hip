@@ -68,11 +68,19 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
     const bool live = b < A.Bt;
     const float gt = (live && A.g_total) ? A.g_total[b] : 0.f;
     const float gl = (live && A.g_last) ? A.g_last[b] : 0.f;
+#ifdef GNS_ABLATE_HBM     // diagnostic: every workgroup re-reads / re-writes the rows of 4 buses of one state slot (cache resident): what the HBM stream costs
+    auto state_row = [&](int slot, int n) { return (((long long)0 * A.G + g) * N + (n & 3)) * RB; };
+#else
     auto state_row = [&](int slot, int n) { return (((long long)slot * A.G + g) * N + n) * RB; };
+#endif
     // rows per bus: (vbar, thbar, dpbar, -) | input-adjoint sums of this step | [single phi: adjoint of the hidden sum] | mbar
     constexpr int RHB = MULTI ? 0 : C::HQ;
     constexpr int RBA = RB + 1 + RHB, RM = 2 + RHB;
+#ifdef GNS_ABLATE_HBM
+    auto adj_row = [&](int n) { return (g * N + (n & 3)) * RBA; };
+#else
     auto adj_row = [&](int n) { return (g * N + n) * RBA; };
+#endif
     auto slot_ptr = [&](int j, int p) { return A.slots + ((g * 6 + j) * E + p) * GNS_LANES + lane; };
     const f4 gsum = *row_ptr(IN, row_grid, lane);
 
@@ -298,7 +306,11 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
           load_pairs<D>(A.state, rr + 1, lane, m);
           f2 macc[D / 2];                                     // d/dm_{k+1} (identity path main.py:188), keeps accumulating
           load_pairs<D>(A.adj, ar + RM, lane, macc);
+#ifdef GNS_ABLATE_HBM
+          load_pairs<H>(A.msg, ((((long long)0 * A.G + g) * N + (n & 3)) * C::NPHI + fphi) * C::HQ, lane, S);
+#else
           load_pairs<H>(A.msg, ((((long long)k * A.G + g) * N + n) * C::NPHI + fphi) * C::HQ, lane, S);
+#endif
           const int p0 = in_ptr[n], p1 = in_ptr[n + 1];
           xs[0] = f2{s0.x, s0.y}; xs[1] = f2{s0.z, s0.w};
           xs[XL - 1] = f2{(float)(p1 - p0), 1.f};             // deg, and the 1 whose column of dW1 is db1
@@ -355,7 +367,11 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
 #pragma unroll
             for (int j = 0; j < H / 2; ++j) G1[j] = f2{0.f, 0.f};
             for (int p = p0; p < p1; ++p) {
+#ifdef GNS_ABLATE_HBM
+              const f4 ea = *row_ptr(IN, row_ein + 3LL * (p & 3), lane), eb = *row_ptr(IN, row_ein + 3LL * (p & 3) + 1, lane);
+#else
               const f4 ea = *row_ptr(IN, row_ein + 3LL * p, lane), eb = *row_ptr(IN, row_ein + 3LL * p + 1, lane);
+#endif
               const f2 xt[3] = {f2{ea.x, ea.y}, f2{ea.z, ea.w}, f2{eb.x, 0.f}};
               f2 a1[H / 2], a2[H / 2], g2[H / 2], g1[H / 2];
               phi_tail<PIN, H, D>(ptb, uh, xt, a1, a2);

@@ -57,10 +57,14 @@ __device__ __forceinline__ void stream_pairs(cfp p, F&& f) {
     f16v& n1 = (c & 1) ? a1 : b1;
     touch(c0);
     touch(c1);
+#ifdef GNS_ABLATE_SLOAD   // diagnostic: the stream keeps re-using its first 32 floats (wrong numbers, no scalar-load latency)
+    if constexpr (c + 1 < NST) { n0 = c0; n1 = c1; }
+#else
     if constexpr (c + 1 < NST) {
       n0 = *(VP)(p + 32 * (c + 1));
       n1 = *(VP)(p + 32 * (c + 1) + 16);
     }
+#endif
     __builtin_amdgcn_sched_barrier(0);
     static_for<0, 16>([&](auto t_) {
       constexpr int t = decltype(t_)::value;

@@ -590,3 +590,4 @@ __device__ __forceinline__ void gws_stage(int lane, const f32x4& Dt, float* stag
     if (idx >= 0) stage[idx] = Dt[r];
   }
 }
+

@@ -455,13 +455,16 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
 template <int D, int H, bool MULTI>
 static int launch_forward_t(const GnsFwdArgs& A, int threads, hipStream_t st) {
   const size_t dyn = A.plane ? (size_t)A.N * GNS_LANES * sizeof(f2) : 0;
-  static bool attr_set[64] = {};                                     // > 64 KB of dynamic LDS needs the opt-in, once per kernel and device
+  static_assert(sizeof(float) * 2 * GNS_MAXW * GNS_LANES * 2 + 2 * sizeof(int) <= GNS_FWD_STATIC_LDS_BYTES, "static LDS of the forward kernel");
+  static bool attr_ok[64] = {};                                      // > 64 KB of dynamic LDS needs the opt-in, once per kernel and device
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (!attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gns_forward_kernel<D, H, MULTI>), hipFuncAttributeMaxDynamicSharedMemorySize, GNS_PLANE_MAX_BYTES);
-    (void)hipGetLastError();
-    attr_set[dev] = true;
+  if (dyn > 64 * 1024 && !attr_ok[dev]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gns_forward_kernel<D, H, MULTI>), hipFuncAttributeMaxDynamicSharedMemorySize, GNS_PLANE_MAX_BYTES) != hipSuccess) {
+      (void)hipGetLastError();
+      return GNS_ELAUNCH;
+    }
+    attr_ok[dev] = true;
   }
   hipLaunchKernelGGL((gns_forward_kernel<D, H, MULTI>), dim3((unsigned)A.G), dim3(threads), dyn, st, A);
   return hipGetLastError() == hipSuccess ? GNS_OK : GNS_ELAUNCH;

@@ -203,16 +203,19 @@ __global__ void __launch_bounds__(MAXT, MINW) gns_gw_forward_kernel(GnsGwFwdArgs
         const float deg = (float)(p1 - p0);
         float th_new = sth, v_new = sv;
         f2 m_new[D / 2];
+        // the L' input [v theta | dp dq | m | sum h | deg] is assembled ONCE per step; only the hidden-sum slots change per family
+        f2 x[(C::LF_IN + 1) / 2];
+        x[0] = f2{sv, sth}; x[1] = f2{sdp, sdq};
+#pragma unroll
+        for (int i = 0; i < D / 2; ++i) x[2 + i] = m[i];
+        x[2 + D / 2 + H / 2] = f2{deg, 0.f};
         static_for<0, 3>([&](auto l_) {
           constexpr int l = decltype(l_)::value;                    // L_theta, L_v, L_m (main.py:173-180)
           constexpr int fphi = MULTI ? (l == 0 ? 1 : (l == 1 ? 0 : 2)) : 0;   // phi_theta, phi_v, phi_m
-          f2 x[(C::LF_IN + 1) / 2];                                 // [v theta | dp dq | m | sum h | deg]
-          x[0] = f2{sv, sth}; x[1] = f2{sdp, sdq};
+          if constexpr (MULTI || l == 0) {
 #pragma unroll
-          for (int i = 0; i < D / 2; ++i) x[2 + i] = m[i];
-#pragma unroll
-          for (int q = 0; q < H / 2; ++q) x[2 + D / 2 + q] = S[fphi * (H / 2) + q];
-          x[2 + D / 2 + H / 2] = f2{deg, 0.f};
+            for (int q = 0; q < H / 2; ++q) x[2 + D / 2 + q] = S[fphi * (H / 2) + q];
+          }
           f2 a1[H / 2], a2[H / 2];
           if constexpr (l < 2) {
             f2 y[1];
@@ -223,7 +226,7 @@ __global__ void __launch_bounds__(MAXT, MINW) gns_gw_forward_kernel(GnsGwFwdArgs
             f2 y[D / 2];
             mlp_fwd<C::LF_IN, H, D>(PT + A.t_off[NPHI + 2] + koff * A.t_sz[NPHI + 2], x, a1, a2, y);
 #pragma unroll
-            for (int i = 0; i < D / 2; ++i) m_new[i] = m[i] + y[i];              // main.py:188
+            for (int i = 0; i < D / 2; ++i) m_new[i] = x[2 + i] + y[i];          // main.py:188
           }
         });
         sv = v_new; sth = th_new;

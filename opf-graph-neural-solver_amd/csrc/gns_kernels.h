@@ -8,7 +8,10 @@
 #define GNS_FWD_MAX_THREADS 1024 // register budget of the forward kernel: 128 VGPRs -> 4 waves/SIMD
 #define GNS_BWD_THREADS 512
 #define GNS_MAX_K 64
-#define GNS_PLANE_MAX_BYTES (144 * 1024)   // forward: LDS budget of the (v, theta) plane; larger cases read neighbours from HBM
+// forward (lane-per-grid): LDS budget of the dynamic (v, theta) plane = the CU's 160 KiB minus the kernel's static LDS
+// (red[2][GNS_MAXW][64][2] floats + the unit counters); larger cases read neighbours from HBM
+#define GNS_FWD_STATIC_LDS_BYTES (2 * GNS_MAXW * GNS_LANES * 2 * 4 + 64)
+#define GNS_PLANE_MAX_BYTES (160 * 1024 - GNS_FWD_STATIC_LDS_BYTES)
 
 // (latent_dim, hidden_dim) pairs with compiled kernels
 #define GNS_FOR_EACH_DIMS(X) X(20, 10) X(10, 10)

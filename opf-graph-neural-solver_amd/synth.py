@@ -22,7 +22,9 @@ import math
 import numpy as np
 import torch
 
-CASE_SHAPES = {14: (14, 20, 5), 30: (30, 41, 6), 118: (118, 186, 54), 300: (300, 411, 69)}
+# 200 is not a reference case: a case-shaped synthetic grid between case118 and case300 (exercises the 64-160 KB LDS plane of the
+# lane-per-grid forward, which case118 (59 KB) and case300 (HBM path) both miss)
+CASE_SHAPES = {14: (14, 20, 5), 30: (30, 41, 6), 118: (118, 186, 54), 200: (200, 290, 45), 300: (300, 411, 69)}
 BASE_MVA = 100.0
 
 # IEEE 14-bus test system (public data): from, to, r, x, b

@@ -342,6 +342,41 @@ def test_resident_batch_is_packed_once_and_repacked_when_it_changes():
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('mapping', ['lane-per-grid', 'grid-per-workgroup'])
+def test_mid_size_case_between_118_and_300_buses(mapping):
+    """A 200-bus synthetic case: the lane-per-grid forward keeps its (v, theta) plane in 100 KB of dynamic LDS (the > 64 KB
+    opt-in path that case118 and case300 both miss); four waves per grid in the grid-per-workgroup kernels.  Outputs and
+    gradients against the CPU oracle."""
+    import opf_graph_neural_solver_amd as amd
+    from oracle import gns_oracle as orc
+    code = 1 if mapping == 'lane-per-grid' else 2
+    old = amd.get_option('fwd_mapping'), amd.get_option('train_mapping')
+    amd.set_option('fwd_mapping', code); amd.set_option('train_mapping', code)
+    try:
+        torch.manual_seed(6)
+        m = amd.GNS(20, 10, 3, 0.9, True).cuda()
+        bu, li, ge = amd.synth.synth_grids(200, 70, seed=8, device='cuda')
+        with torch.no_grad():
+            ev = m(bu, li, ge)
+        v, th, tot, last = m(bu, li, ge)
+        tot.mean().backward()
+        grad = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).cpu()
+    finally:
+        amd.set_option('fwd_mapping', old[0]); amd.set_option('train_mapping', old[1])
+    flat = m.flat_parameters().detach().cpu()
+    g_o = torch.zeros_like(flat)
+    for b in (0, 33, 69):
+        f = flat.clone().requires_grad_(True)
+        o = orc.gns_forward(orc.unflatten_params(f, 20, 10, 3, True), bu[b].cpu(), li[b].cpu(), ge[b].cpu(), latent_dim=20, K=3, gamma=0.9, multiple_phi=True)
+        for mine, ref, what in ((v[b], o[0], 'v'), (th[b], o[1], 'theta'), (tot[b], o[2], 'total'), (ev[0][b], o[0], 'v eval'), (ev[1][b], o[1], 'theta eval')):
+            assert_close(mine.detach().cpu(), ref.detach(), REL, what=f'{what}[{b}]')
+    for b in range(70):
+        f = flat.clone().requires_grad_(True)
+        (orc.gns_forward(orc.unflatten_params(f, 20, 10, 3, True), bu[b].cpu(), li[b].cpu(), ge[b].cpu(), latent_dim=20, K=3, gamma=0.9, multiple_phi=True)[2] / 70.0).backward()
+        g_o += f.grad
+    assert_close(grad, g_o, 5e-5, abs_floor=1e-7, what='grad_params')
+
+
 def test_in_place_parameter_update_between_forward_and_backward_raises():
     """forward / optimizer.step() (or any in-place parameter write) / backward mixes weights packed by the forward with the
     live buffer; torch autograd raises in that situation and so must the fused path."""
