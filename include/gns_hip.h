@@ -79,6 +79,7 @@ int gns_workspace_bytes(const gns_config* cfg, int64_t Bt, int save_state, size_
  * gns_backward then read through `packed_inputs` instead of re-packing on every call (the batch-invariant prologue of
  * main.py:144-152 and the bus-id-as-line-index gathers of main.py:38,41).  Pass NULL to pack per call.  The buffer is only
  * valid for the tensors it was made from; the grid-per-workgroup kernels read the caller's tensors directly and ignore it. */
+int gns_uses_packed_inputs(const gns_config* cfg, int64_t Bt, int save_state);   /* 1: the call would run the kernels that read `packed_inputs` */
 int gns_prepack_bytes(const gns_config* cfg, int64_t Bt, size_t* bytes);
 int gns_prepack(const gns_config* cfg, const void* topo_dev, const float* buses, const float* lines,
                 const float* generators, int64_t Bt, void* packed, size_t packed_bytes, void* stream);

@@ -50,6 +50,7 @@ def load_library():
     lib.gns_prepare_topology.argtypes = [i32, i32, i32, vp, vp, vp, vp, sz]
     lib.gns_workspace_bytes.argtypes = [cfgp, i64, ctypes.c_int, ctypes.POINTER(sz), ctypes.POINTER(sz)]
     lib.gns_forward.argtypes = [cfgp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, sz, ctypes.c_int, vp]
+    lib.gns_uses_packed_inputs.argtypes = [cfgp, i64, ctypes.c_int]
     lib.gns_prepack_bytes.argtypes = [cfgp, i64, ctypes.POINTER(sz)]
     lib.gns_prepack.argtypes = [cfgp, vp, vp, vp, vp, i64, vp, sz, vp]
     lib.gns_backward.argtypes = [cfgp, vp, vp, vp, vp, vp, i64, vp, vp, sz, vp, vp, vp, vp, vp, vp, sz, vp]
@@ -59,7 +60,7 @@ def load_library():
     lib.gns_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
     for f in ('gns_profile_enable', 'gns_profile_read', 'gns_param_count', 'gns_config_supported', 'gns_topology_bytes', 'gns_prepare_topology',
               'gns_workspace_bytes', 'gns_forward', 'gns_backward', 'gns_profile_enable', 'gns_profile_read',
-              'gns_set_option', 'gns_get_option', 'gns_prepack_bytes', 'gns_prepack'):
+              'gns_set_option', 'gns_get_option', 'gns_prepack_bytes', 'gns_prepack', 'gns_uses_packed_inputs'):
         getattr(lib, f).restype = ctypes.c_int
     _LIB = lib
     return lib
@@ -67,7 +68,7 @@ def load_library():
 
 EXPORTS = ('gns_version', 'gns_param_count', 'gns_config_supported', 'gns_topology_bytes', 'gns_prepare_topology',
            'gns_workspace_bytes', 'gns_forward', 'gns_backward', 'gns_profile_enable', 'gns_profile_read',
-           'gns_set_option', 'gns_get_option', 'gns_prepack_bytes', 'gns_prepack')
+           'gns_set_option', 'gns_get_option', 'gns_prepack_bytes', 'gns_prepack', 'gns_uses_packed_inputs')
 
 
 def set_option(name: str, value: int) -> None:

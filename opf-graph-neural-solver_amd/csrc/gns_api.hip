@@ -107,6 +107,22 @@ static int gw_train_pack(const gns_config* c, int64_t Bt) {
   const int64_t groups = (Bt + GNS_LANES - 1) / GNS_LANES;
   return (groups <= 96 && gns_gw_backward_wpg(c->n_bus) <= 2) ? P : 0;
 }
+// Grids per workgroup of the evaluation-mode forward when it runs on the grid-per-workgroup kernel, 0 when the lane-per-grid
+// kernel runs it.  gns_workspace_bytes, gns_forward and gns_uses_packed_inputs must agree, so they all ask here.
+static int gw_eval_pack(const gns_config* c) {
+  const GnsTuning& T = tuning();
+  const int N = c->n_bus, E = c->n_line;
+  int P = T.gw_pack;
+  if (P <= 0) {                                   // auto: one workgroup per CU with as many grids as fit (all waves of a CU in the
+    P = 1;                                        // same phase stream the same weights: 73 % scalar-cache hits against 55 %)
+    const int wpg = ((N > E ? N : E) + 63) / 64;
+    for (int q = 2; q * wpg <= 12; ++q) if (gns_gw_supported(N, E, c->latent_dim, c->hidden_dim, c->multiple_phi, q)) P = q;
+  }
+  const bool can = T.gw_ready && gns_gw_supported(N, E, c->latent_dim, c->hidden_dim, c->multiple_phi, P);
+  const bool want = T.fwd_mapping == 2 || (T.fwd_mapping == 0 && N >= 48);
+  return (can && want) ? P : 0;
+}
+
 struct GwTrainLayout { size_t off_pt, off_pn, off_save; GwSaveLayout sv; size_t fwd_total; int blocks, waves; size_t off_slab, off_part, off_tmp, bwd_total; long long slab_floats, nslab; };
 static GwTrainLayout gw_train_layout(const gns_config* c, int64_t Bt, int P) {
   GwTrainLayout L;
@@ -188,6 +204,11 @@ extern "C" int gns_workspace_bytes(const gns_config* cfg, int64_t Bt, int save_s
     if (bwd_bytes) *bwd_bytes = G.bwd_total;
     return GNS_OK;
   }
+  if (!save_state && gw_eval_pack(cfg) > 0) {                      // state on chip, inputs read in place: only the parameter streams
+    if (fwd_bytes) *fwd_bytes = L.off_in;
+    if (bwd_bytes) *bwd_bytes = 0;
+    return GNS_OK;
+  }
   if (fwd_bytes) *fwd_bytes = L.total;
   if (bwd_bytes) {
     GnsBwdLayout B;
@@ -195,6 +216,11 @@ extern "C" int gns_workspace_bytes(const gns_config* cfg, int64_t Bt, int save_s
     *bwd_bytes = B.total;
   }
   return GNS_OK;
+}
+
+extern "C" int gns_uses_packed_inputs(const gns_config* cfg, int64_t Bt, int save_state) {
+  if (check_cfg(cfg) != GNS_OK || Bt <= 0) return 0;
+  return (save_state ? gw_train_pack(cfg, Bt) : gw_eval_pack(cfg)) > 0 ? 0 : 1;
 }
 
 extern "C" int gns_prepack_bytes(const gns_config* cfg, int64_t Bt, size_t* bytes) {
@@ -254,7 +280,7 @@ extern "C" int gns_forward(const gns_config* cfg, const void* topo_dev, const fl
   }
   GnsFwdLayout L;
   gns_fwd_layout(N, E, d, h, K, cfg->multiple_phi, Bt, save_state, &L);
-  if (workspace_bytes < L.total) return GNS_ESIZE;
+  if (workspace_bytes < ((!save_state && gw_eval_pack(cfg) > 0) ? L.off_in : L.total)) return GNS_ESIZE;
   float* pt = (float*)(ws + L.off_pt);
   float* pn = (float*)(ws + L.off_pn);
   float* pin = (float*)(ws + L.off_in);
@@ -262,15 +288,8 @@ extern "C" int gns_forward(const gns_config* cfg, const void* topo_dev, const fl
   if (rc != GNS_OK) return rc;
   // Evaluation (nothing saved for a backward): the grid-per-workgroup mapping keeps the whole state on chip.
   {
-    int P = T.gw_pack;
-    if (P <= 0) {                                   // auto: one workgroup per CU with as many grids as fit (all waves of a CU in the
-      P = 1;                                        // same phase stream the same weights: 73 % scalar-cache hits against 55 %)
-      const int wpg = ((N > E ? N : E) + 63) / 64;
-      for (int q = 2; q * wpg <= 12; ++q) if (gns_gw_supported(N, E, d, h, cfg->multiple_phi, q)) P = q;
-    }
-    const bool can = !save_state && T.gw_ready && gns_gw_supported(N, E, d, h, cfg->multiple_phi, P);
-    const bool want = T.fwd_mapping == 2 || (T.fwd_mapping == 0 && N >= 48);
-    if (can && want) {
+    const int P = save_state ? 0 : gw_eval_pack(cfg);
+    if (P > 0) {
       GnsGwFwdArgs G;
       std::memset(&G, 0, sizeof(G));
       G.topo = (const int*)topo_dev; G.pt = pt; G.buses = buses; G.lines = lines; G.gens = generators;

@@ -97,7 +97,7 @@ class _GNSFunction(torch.autograd.Function):
         flat = mod._exec_flat(dev)                       # the parameters themselves, or their device mirror for a CPU-resident model
         with torch.cuda.device(dev):                     # the launch must land on the tensors' device, whatever the current device is
             stream = torch.cuda.current_stream(dev).cuda_stream
-            packed = mod._packed_inputs(lib, cfg, topo, buses, lines, gens, stream)
+            packed = mod._packed_inputs(lib, cfg, topo, buses, lines, gens, stream, need_grad)
             _check(lib.gns_forward(ctypes.byref(cfg), topo.blob.data_ptr(), flat.data_ptr(), buses.data_ptr(), lines.data_ptr(),
                                    gens.data_ptr(), Bt, None if packed is None else packed.data_ptr(),
                                    v.data_ptr(), theta.data_ptr(), total.data_ptr(), last.data_ptr(),
@@ -235,9 +235,9 @@ class GNS(nn.Module):
         mir.copy_(flat, non_blocking=False)
         return mir
 
-    def _packed_inputs(self, lib, cfg, topo, buses, lines, gens, stream):
-        if not self.cache_packed_inputs:
-            return None
+    def _packed_inputs(self, lib, cfg, topo, buses, lines, gens, stream, need_grad):
+        if not self.cache_packed_inputs or not lib.gns_uses_packed_inputs(ctypes.byref(cfg), buses.shape[0], int(need_grad)):
+            return None                              # (the grid-per-workgroup kernels read the caller's tensors in place)
         key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (buses, lines, gens)) + (id(topo),)
         ent = self._pack_cache
         if ent is not None and ent[0] == key:

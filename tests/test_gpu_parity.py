@@ -320,6 +320,8 @@ def test_resident_batch_is_packed_once_and_repacked_when_it_changes():
     torch.manual_seed(0)
     m = amd.GNS(20, 10, 3, 0.9, True).cuda()
     bu, li, ge = amd.synth.synth_grids(118, 300, seed=4, device='cuda')
+    old_map = amd.get_option('train_mapping')
+    amd.set_option('train_mapping', 1)                 # the lane-per-grid kernels are the ones that read the packed layout
 
     def run():
         m.zero_grad()
@@ -337,9 +339,19 @@ def test_resident_batch_is_packed_once_and_repacked_when_it_changes():
     changed = run()
     m.cache_packed_inputs = False
     fresh = run()
+    amd.set_option('train_mapping', old_map)
     assert not torch.equal(changed[2], base[2])
     for a, b in zip(changed, fresh):
         assert torch.equal(a, b)
+    # the grid-per-workgroup kernels read the caller's tensors in place: nothing is packed for them
+    m._pack_cache = None
+    m.cache_packed_inputs = True
+    amd.set_option('train_mapping', 2)
+    try:
+        m(bu, li, ge)[2].mean().backward()
+    finally:
+        amd.set_option('train_mapping', old_map)
+    assert m._pack_cache is None
 
 
 @pytest.mark.parametrize('mapping', ['lane-per-grid', 'grid-per-workgroup'])
