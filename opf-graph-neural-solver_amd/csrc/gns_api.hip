@@ -378,7 +378,9 @@ extern "C" int gns_backward(const gns_config* cfg, const void* topo_dev, const f
   char* bw = (char*)bwd_workspace;
   const int blocks = (int)(B.groups < GNS_BWD_MAX_WG ? B.groups : GNS_BWD_MAX_WG);
   const long long nslab = (long long)blocks * GNS_BWD_WAVES;
-  if (hipMemsetAsync(bw + B.off_slab, 0, (size_t)nslab * B.slab_floats * 4, st) != hipSuccess) return GNS_ELAUNCH;
+  // the V2 sweep writes every slab entry itself on a workgroup's first group: no 90 MB memset in front of it
+  const bool v2 = tuning().dw_mfma && tuning().bwd_variant == 2 && cfg->multiple_phi;
+  if (!v2 && hipMemsetAsync(bw + B.off_slab, 0, (size_t)nslab * B.slab_floats * 4, st) != hipSuccess) return GNS_ELAUNCH;
   GnsBwdArgs A;
   std::memset(&A, 0, sizeof(A));
   A.topo = (const int*)topo_dev;
@@ -394,6 +396,7 @@ extern "C" int gns_backward(const gns_config* cfg, const void* topo_dev, const f
   for (int k = 0; k < K; ++k) A.gw[k] = (float)std::pow((double)cfg->gamma, (double)(K - k));
   A.Bt = Bt; A.G = B.groups; A.slab_floats = B.slab_floats; A.N = N; A.E = E; A.K = K;
   A.part_idx = gns_part_index(GNS_BWD_WAVES);
+  A.slab_dirty = v2 ? 1 : 0;
   prof_mark(1, true, st);
   // The weight-gradient contraction over the grids runs on the matrix pipe (exact fp32) unless GNS_DW_MFMA=0 asks for
   // the packed-FMA register tiles; both are parity-tested (gns_backward.hip, "weight-gradient engines").

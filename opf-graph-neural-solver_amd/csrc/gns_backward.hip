@@ -62,7 +62,16 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
 #else
 #define STAMP(i)
 #endif
+  if constexpr (V2) {
+    if (A.slab_dirty) {     // the two blocks no sweep touches (L_m.{K-1}, phi_m.{K-1}: no gradient in the reference) must still read as zero
+      float* z0 = slab + A.g_off[C::NPHI + 2] + (long long)(K - 1) * A.g_sz[C::NPHI + 2];
+      for (int i = lane; i < (int)A.g_sz[C::NPHI + 2]; i += 64) z0[i] = 0.f;
+      float* z1 = slab + A.g_off[2] + (long long)(K - 1) * A.g_sz[2];
+      for (int i = lane; i < (int)A.g_sz[2]; i += 64) z1[i] = 0.f;
+    }
+  }
   for (long long g = blockIdx.x; g < A.G; g += gridDim.x) {
+    const bool first_store = V2 && A.slab_dirty && g == (long long)blockIdx.x;
     const long long in_base = g * R, row_ein = in_base + 3LL * N, row_eout = row_ein + 3LL * E, row_grid = row_eout + E;
     const long long b = g * GNS_LANES + lane;
     const bool live = b < A.Bt;
@@ -406,16 +415,16 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
           constexpr int ob1 = LIN * H, oW2 = ob1 + H, ob2 = oW2 + H * H, oW4 = ob2 + H, ob4 = oW4 + OUT * H;
           float* lb_ = slab + A.g_off[C::NPHI + l] + koff * A.g_sz[C::NPHI + l];
           static_for<0, NB1>([&](auto t_) { constexpr int t = decltype(t_)::value;
-            gws_flush(lane, T1[t], lb_, [&](int c, int il) { const int i = 16 * t + il; return c < H ? (i < LIN ? c * LIN + i : (i == LIN ? ob1 + c : -1)) : -1; }); });
-          gws_flush(lane, T2, lb_, [&](int c, int il) { return c < H ? (il < H ? oW2 + c * H + il : (il == H ? ob2 + c : -1)) : -1; });
+            gws_flush(lane, T1[t], lb_, [&](int c, int il) { const int i = 16 * t + il; return c < H ? (i < LIN ? c * LIN + i : (i == LIN ? ob1 + c : -1)) : -1; }, first_store); });
+          gws_flush(lane, T2, lb_, [&](int c, int il) { return c < H ? (il < H ? oW2 + c * H + il : (il == H ? ob2 + c : -1)) : -1; }, first_store);
           static_for<0, NA4>([&](auto t_) { constexpr int t = decltype(t_)::value;
-            gws_flush(lane, T4[t], lb_, [&](int c, int il) { const int j = 12 * t + c; return (c < 12 && j < OUT) ? (il < H ? oW4 + j * H + il : (il == H ? ob4 + j : -1)) : -1; }); });
+            gws_flush(lane, T4[t], lb_, [&](int c, int il) { const int j = 12 * t + c; return (c < 12 && j < OUT) ? (il < H ? oW4 + j * H + il : (il == H ? ob4 + j : -1)) : -1; }, first_store); });
           constexpr int pb1 = PIN * H, pW2 = pb1 + H, pb2 = pW2 + H * H;
           float* pb_ = slab + A.g_off[fphi] + koff * A.g_sz[fphi];
-          gws_flush(lane, TP1, pb_, [&](int c, int il) { return c < H ? (il < PIN - D ? c * PIN + D + il : (il == PIN - D ? pb1 + c : -1)) : -1; });
-          gws_flush(lane, TP2, pb_, [&](int c, int il) { return c < H ? (il < H ? pW2 + c * H + il : (il == H ? pb2 + c : -1)) : -1; });
+          gws_flush(lane, TP1, pb_, [&](int c, int il) { return c < H ? (il < PIN - D ? c * PIN + D + il : (il == PIN - D ? pb1 + c : -1)) : -1; }, first_store);
+          gws_flush(lane, TP2, pb_, [&](int c, int il) { return c < H ? (il < H ? pW2 + c * H + il : (il == H ? pb2 + c : -1)) : -1; }, first_store);
           static_for<0, NDM>([&](auto t_) { constexpr int t = decltype(t_)::value;
-            gws_flush(lane, TPm[t], pb_, [&](int c, int il) { const int i = 16 * t + il; return (c < H && i < D) ? c * PIN + i : -1; }); });
+            gws_flush(lane, TPm[t], pb_, [&](int c, int il) { const int i = 16 * t + il; return (c < H && i < D) ? c * PIN + i : -1; }, first_store); });
         }
         STAMP(5 + l)
       });

@@ -572,12 +572,12 @@ __device__ __forceinline__ void gws_pass(const float* rec, int lane, f32x4& Dt) 
 }
 // slab_blk[idx_of(c, i)] += D[c][i] for the entries that map to a parameter (idx_of returns -1 otherwise)
 template <class F>
-__device__ __forceinline__ void gws_flush(int lane, const f32x4& Dt, float* blk, F&& idx_of) {
+__device__ __forceinline__ void gws_flush(int lane, const f32x4& Dt, float* blk, F&& idx_of, bool store = false) {
   const int cl = 4 * (lane >> 4), il = lane & 15;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int idx = idx_of(cl + r, il);
-    if (idx >= 0) blk[idx] += Dt[r];
+    if (idx >= 0) blk[idx] = store ? Dt[r] : blk[idx] + Dt[r];     // store: the slab was not zeroed and this is its first use
   }
 }
 // stage[idx_of(c, i)] = D[c][i]: the wave's LDS stage of a gradient block (every entry is produced exactly once per use)

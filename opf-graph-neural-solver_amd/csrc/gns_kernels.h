@@ -59,6 +59,7 @@ struct GnsBwdArgs {
   float gw[GNS_MAX_K];
   long long Bt, G, slab_floats;
   int N, E, K, part_idx;
+  int slab_dirty;                        // 1: the slabs were NOT zeroed by the caller; the V2 sweep stores (instead of adding) on a workgroup's first group
 };
 
 int gns_launch_backward(int d, int h, int multi, int mfma, int variant, const GnsBwdArgs& A, int blocks, hipStream_t st);

@@ -105,7 +105,8 @@ class _GNSFunction(torch.autograd.Function):
         if need_grad:
             ctx.cfg, ctx.topo, ctx.ws, ctx.flat, ctx.Bt, ctx.bwd_bytes = cfg, topo, ws, flat, Bt, bwd_b.value
             ctx.params = params
-            ctx.param_versions = tuple(p._version for p in params)
+            ctx.mod_flat = mod._flat
+            ctx.param_versions = tuple(p._version for p in params) + (mod._flat._version,)   # (a flat optimiser writes through the buffer)
             ctx.inputs = (buses, lines, gens)          # the backward of the grid-per-workgroup mapping re-reads them
             ctx.packed = packed
             ctx.shapes = [p.shape for p in params]
@@ -117,7 +118,7 @@ class _GNSFunction(torch.autograd.Function):
         flat = ctx.flat
         # the backward mixes weights packed by the forward with the live buffer: an in-place update in between (an
         # optimizer.step(), p.add_()) would give silently inconsistent gradients where torch autograd raises
-        if tuple(p._version for p in ctx.params) != ctx.param_versions:
+        if tuple(p._version for p in ctx.params) + (ctx.mod_flat._version,) != ctx.param_versions:
             raise GNSError('parameters were modified in place between forward and backward')
         dev = flat.device
         grad = torch.zeros_like(flat)

@@ -17,14 +17,67 @@ def checkpoint_name(case_nr, K, latent_dim, hidden_dim, multiple_phi, optimizer_
     return f'best_model_c{case_nr}_K{K}_L{latent_dim}_H{hidden_dim}_{multiple_phi}_optim{optimizer_name}.pth'
 
 
-def make_optimizer(model, optimizer_name='Adam', lr=None):
-    """``main.py:236-243``: Adagrad with lr 0.01, otherwise Adam with lr 0.001."""
-    if optimizer_name == 'Adagrad':
-        return torch.optim.Adagrad(model.parameters(), lr=0.01 if lr is None else lr)
-    # same update rule as the reference's torch.optim.Adam; on the GPU the single-kernel ("fused") implementation replaces
-    # ~10 multi-tensor launches over the 144 parameter tensors
+class FlatOptimizer:
+    """The reference's optimiser (``torch.optim.Adam`` / ``Adagrad``, ``main.py:236-243``) run on the model's ONE flat
+    parameter buffer instead of its 144 tensors: the parameters are views of that buffer (``GNS.flat_parameters``) and the
+    fused backward hands their gradients as views of one flat gradient (``dist.flat_gradient``), so the element-wise update
+    is the same arithmetic in one kernel launch instead of six multi-tensor chunks (34 -> 6 us per step on MI355X).
+    ``step()`` / ``zero_grad()`` like a torch optimiser; ``state_dict`` is that of the inner optimiser over the flat tensor
+    (the model's own ``state_dict`` - what the reference checkpoints, ``main.py:308`` - is unaffected)."""
+
+    def __init__(self, model, inner_cls, **kw):
+        self.model = model
+        self._cls, self._kw = inner_cls, kw
+        self._flat = None
+        self.inner = None
+        self._bind()
+
+    def _bind(self):
+        flat = self.model.flat_parameters()
+        if self._flat is None or self._flat.data_ptr() != flat.data_ptr() or self._flat.device != flat.device:
+            # (re)built when .to() / load_state_dict replaced the storage; the moment estimates restart with it
+            self._flat = torch.nn.Parameter(flat.detach(), requires_grad=True)     # shares the storage
+            self.inner = self._cls([self._flat], **self._kw)
+
+    def step(self):
+        from . import dist as gdist
+        self._bind()
+        self._flat.grad = gdist.flat_gradient(self.model)
+        self.inner.step()
+        # the update went through an alias of the buffer: tell autograd's bookkeeping (the fused backward refuses to mix
+        # weights packed before an update with the live buffer, like torch autograd would)
+        torch.autograd.graph.increment_version(self.model.flat_parameters())
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.model.parameters():
+            p.grad = None
+        if self._flat is not None:
+            self._flat.grad = None
+
+    def state_dict(self):
+        return self.inner.state_dict()
+
+    def load_state_dict(self, sd):
+        self.inner.load_state_dict(sd)
+
+    @property
+    def param_groups(self):
+        return self.inner.param_groups
+
+
+def make_optimizer(model, optimizer_name='Adam', lr=None, flat=None):
+    """``main.py:236-243``: Adagrad with lr 0.01, otherwise Adam with lr 0.001.  ``flat`` (default: on for a model that
+    lives on the GPU) runs the same update on the flat parameter buffer in one launch (``FlatOptimizer``)."""
     on_gpu = all(p.is_cuda for p in model.parameters())
-    return torch.optim.Adam(model.parameters(), lr=0.001 if lr is None else lr, fused=on_gpu)
+    if flat is None:
+        flat = on_gpu and hasattr(model, 'flat_parameters')
+    if optimizer_name == 'Adagrad':
+        kw, cls = dict(lr=0.01 if lr is None else lr), torch.optim.Adagrad
+    else:
+        kw, cls = dict(lr=0.001 if lr is None else lr, fused=on_gpu), torch.optim.Adam
+    if flat:
+        return FlatOptimizer(model, cls, **kw)
+    return cls(model.parameters(), **kw)
 
 
 def train_step(model, optimizer, buses, lines, generators, global_batch=None):

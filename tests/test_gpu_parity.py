@@ -389,6 +389,36 @@ def test_mid_size_case_between_118_and_300_buses(mapping):
     assert_close(grad, g_o, 5e-5, abs_floor=1e-7, what='grad_params')
 
 
+def test_flat_optimizer_is_the_reference_optimizer_in_one_launch():
+    """training.make_optimizer on a GPU model runs torch.optim.Adam on the ONE flat parameter buffer: the same weights as
+    torch.optim.Adam(model.parameters()) after a few steps, the in-place guard still fires between forward and backward."""
+    import opf_graph_neural_solver_amd as amd
+    bu, li, ge = amd.synth.synth_grids(30, 64, seed=12, device='cuda')
+    ws = []
+    for flat in (True, False):
+        torch.manual_seed(7)
+        m = amd.GNS(20, 10, 3, 0.9, True).cuda()
+        opt = amd.training.make_optimizer(m, flat=flat)
+        assert isinstance(opt, amd.training.FlatOptimizer) == flat
+        for _ in range(4):
+            opt.zero_grad()
+            m(bu, li, ge)[2].mean().backward()
+            opt.step()
+        ws.append(torch.cat([p.detach().reshape(-1) for p in m.parameters()]).clone())
+    assert float((ws[0] - ws[1]).abs().max()) <= 1e-7 * float(ws[1].abs().max())
+    tot = m(bu, li, ge)[2].mean()
+    torch.manual_seed(7)
+    m2 = amd.GNS(20, 10, 3, 0.9, True).cuda()
+    o2 = amd.training.make_optimizer(m2, flat=True)
+    m2(bu, li, ge)[2].mean().backward(); o2.step()
+    t2 = m2(bu, li, ge)[2].mean()
+    t2.backward(); o2.step()                               # normal order works
+    t3 = m2(bu, li, ge)[2].mean()
+    o2.step()                                              # a step between forward and backward must be refused
+    with pytest.raises(amd.GNSError, match='modified in place'):
+        t3.backward()
+
+
 def test_in_place_parameter_update_between_forward_and_backward_raises():
     """forward / optimizer.step() (or any in-place parameter write) / backward mixes weights packed by the forward with the
     live buffer; torch autograd raises in that situation and so must the fused path."""
