@@ -124,6 +124,8 @@ int gns_profile_read(int backward, float* ms_sum, int* launches);
  *   "gw_pack"     grids per workgroup of the grid-per-workgroup mapping (0 = auto)
  *   "fwd_waves"   waves per workgroup of the lane-per-grid forward (1,2,4,8,16)
  *   "fwd_plane"   0: the lane-per-grid forward gathers neighbour (v, theta) from HBM instead of LDS
+ *   "bwd_variant" family sweep of the lane-per-grid backward: 1 wide half-wave records | 2 layer-wise sweep with sub-record
+ *                 windows (default) | 3 = 2 with the contraction chains issued behind the weight streams
  *   "dw_mfma"     0: weight-gradient contraction on packed FMAs instead of the fp32 matrix pipe
  * Both mappings and both engines compute the same function of the reference (GNS/main.py:140-202, :288). */
 int gns_set_option(const char* name, int value);

@@ -25,7 +25,7 @@ GnsTuning make_tuning() {
   if (const char* e = std::getenv("GNS_FWD_WAVES")) { const int w = std::atoi(e); if (gns_part_index(w) >= 0 && w * 64 <= GNS_FWD_MAX_THREADS) t.fwd_waves = w; }
   if (const char* e = std::getenv("GNS_FWD_PLANE")) t.fwd_plane = e[0] == '0' ? 0 : 1;
   if (const char* e = std::getenv("GNS_DW_MFMA")) t.dw_mfma = e[0] == '0' ? 0 : 1;
-  if (const char* e = std::getenv("GNS_BWD_VARIANT")) { const int v = std::atoi(e); if (v == 1 || v == 2) t.bwd_variant = v; }
+  if (const char* e = std::getenv("GNS_BWD_VARIANT")) { const int v = std::atoi(e); if (v >= 1 && v <= 3) t.bwd_variant = v; }
   if (const char* e = std::getenv("GNS_TRAIN_MAPPING")) t.train_mapping = !std::strcmp(e, "lane") ? 1 : (!std::strcmp(e, "lds") ? 2 : 0);
   t.gw_ready = (gns_gw_init_device() == GNS_OK && gns_gw_backward_init_device() == GNS_OK) ? 1 : 0;
   return t;
@@ -41,7 +41,7 @@ extern "C" int gns_set_option(const char* name, int value) {
   if (!name) return GNS_EINVAL;
   GnsTuning& t = tuning();
   if (!std::strcmp(name, "fwd_mapping")) { if (value < 0 || value > 2) return GNS_EINVAL; t.fwd_mapping = value; return GNS_OK; }
-  if (!std::strcmp(name, "bwd_variant")) { if (value < 1 || value > 2) return GNS_EINVAL; t.bwd_variant = value; return GNS_OK; }
+  if (!std::strcmp(name, "bwd_variant")) { if (value < 1 || value > 3) return GNS_EINVAL; t.bwd_variant = value; return GNS_OK; }
   if (!std::strcmp(name, "train_mapping")) { if (value < 0 || value > 2) return GNS_EINVAL; t.train_mapping = value; return GNS_OK; }
   if (!std::strcmp(name, "gw_pack")) { if (value < 0 || value > 16) return GNS_EINVAL; t.gw_pack = value; return GNS_OK; }
   if (!std::strcmp(name, "fwd_waves")) { if (gns_part_index(value) < 0 || value * 64 > GNS_FWD_MAX_THREADS) return GNS_EINVAL; t.fwd_waves = value; return GNS_OK; }
@@ -379,7 +379,7 @@ extern "C" int gns_backward(const gns_config* cfg, const void* topo_dev, const f
   const int blocks = (int)(B.groups < GNS_BWD_MAX_WG ? B.groups : GNS_BWD_MAX_WG);
   const long long nslab = (long long)blocks * GNS_BWD_WAVES;
   // the V2 sweep writes every slab entry itself on a workgroup's first group: no 90 MB memset in front of it
-  const bool v2 = tuning().dw_mfma && tuning().bwd_variant == 2 && cfg->multiple_phi;
+  const bool v2 = tuning().dw_mfma && tuning().bwd_variant >= 2 && cfg->multiple_phi;
   if (!v2 && hipMemsetAsync(bw + B.off_slab, 0, (size_t)nslab * B.slab_floats * 4, st) != hipSuccess) return GNS_ELAUNCH;
   GnsBwdArgs A;
   std::memset(&A, 0, sizeof(A));

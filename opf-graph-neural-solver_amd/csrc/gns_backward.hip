@@ -24,8 +24,9 @@
 // records), the input adjoints stream out four at a time into their consumers (no 36-register adjoint array), phi' is
 // recomputed as head (once per bus) + tail (per line), and the latent columns of phi's dW1 and d/dm are taken once per bus
 // on the sum of the lines' first-layer adjoints (phi's first layer is linear in m(dst)).
-template <int D, int H, bool MULTI, bool MFMA, bool V2>
+template <int D, int H, bool MULTI, bool MFMA, int VAR>
 __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArgs A) {
+  constexpr bool V2 = VAR >= 2;          // 1: wide half-wave records   2: layer-wise sweep, sub-record windows   3: 2 + contraction chains drained behind the weight streams
   using C = GnsDims<D, H, MULTI>;
   constexpr int RB = C::RB;
   constexpr int W = GNS_BWD_WAVES;
@@ -46,7 +47,7 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
   const long long R = gns_in_rows(N, E);
   const float* IN = A.in;
 
-  constexpr int RECF = V2 ? GwSub::RECF
+  constexpr int RECF = VAR == 3 ? 64 * 76 + 32 : V2 ? GwSub::RECF
                           : gns_cmax(GNS_REC_ROWS * gns_cmax(RecLay<C::LF_IN, H, D>::RS, RecLay<C::LF_IN, H, 1>::RS),
                                      2 * GNS_REC_ROWS * RecLay2<C::PHI_IN, H>::RS) + 32;   // +32: the MFMA variant reads 16-wide column blocks
   __shared__ __attribute__((aligned(16))) float rec_all[W][RECF];
@@ -283,6 +284,208 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
         for (int i = 0; i < D / 2; ++i) x[i] = m[i];
         x[D / 2] = f2{ea.x, ea.y}; x[D / 2 + 1] = f2{ea.z, ea.w}; x[D / 2 + 2] = f2{eb.x, 0.f};
       };
+      if constexpr (VAR == 3) {
+      // ---------------- V3: the V2 sweep with the weight-gradient chains issued in the background of the NEXT weight streams ----
+      static_for<0, 3>([&](auto o_) {
+        constexpr int l = (decltype(o_)::value == 0) ? 2 : decltype(o_)::value - 1;
+        constexpr int fphi = l == 0 ? 1 : (l == 1 ? 0 : 2);
+        constexpr int OUT = (l == 2) ? D : 1, OUTP = OUT + (OUT & 1);
+        constexpr int LIN = C::LF_IN, XL = (LIN + 1) / 2, PIN = C::PHI_IN, SOFF = 2 + D / 2;
+        constexpr int NB1 = (2 * XL + 15) / 16, NA4 = (OUTP + 11) / 12, NDM = (D + 15) / 16;
+        using NL = NLay<LIN, H, OUTP>;
+        if (l == 2 && k == K - 1) return;
+        // windows (all in the wave's record buffer, one at a time):
+        //   L  [g1 0..11 | x,1 12..47 | g2 48..59 | a1,1 60..71]   RS 76   chains: dW2 (T2), dW1 tile t (T1[t])
+        //   E  [g1 0..11 | line parameters,1 12..19 | g2 20..31 | a1,1 32..43]   RS 44   chains: TP1, TP2
+        //   B  [G1 0..11 | m 12..31]   RS 36   chains: TPm[t]
+        using PL = GwProgL<NB1>;
+        using PE = GwProgE;
+        using PB = GwProgB<NDM>;
+        static_assert(PB::LEN <= 45, "the bus window must drain inside the next bus's recomputation");
+        cfp nb = PN + A.n_off[C::NPHI + l] + koff * A.n_sz[C::NPHI + l];
+        cfp pnb = PN + A.n_off[fphi] + koff * A.n_sz[fphi];
+        cfp ptb = PT + A.t_off[fphi] + koff * A.t_sz[fphi];
+        f32x4 T1[NB1], T2, T4[NA4], TP1, TP2, TPm[NDM];
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NB1; ++t) T1[t] = z4;
+#pragma unroll
+        for (int t = 0; t < NA4; ++t) T4[t] = z4;
+#pragma unroll
+        for (int t = 0; t < NDM; ++t) TPm[t] = z4;
+        T2 = z4; TP1 = z4; TP2 = z4;
+        float ra[4], rb[4];                                   // operand ring of the background chains
+        const int rowmap = ((lane >> 5) & 1) + 4 * ((lane >> 4) & 1);
+        const float* baseL = rec + rowmap * PL::RS + (lane & 15);
+        const float* baseE = rec + rowmap * PE::RS + (lane & 15);
+        const float* baseB = rec + rowmap * PB::RS + (lane & 15);
+        auto accL = [&](auto ch_) -> f32x4& { constexpr int ch = decltype(ch_)::value; if constexpr (ch == 0) return T2; else return T1[ch - 1]; };
+        auto accE = [&](auto ch_) -> f32x4& { constexpr int ch = decltype(ch_)::value; if constexpr (ch == 0) return TP1; else return TP2; };
+        auto accB = [&](auto ch_) -> f32x4& { constexpr int ch = decltype(ch_)::value; return TPm[ch]; };
+        auto putw = [&](int rs, int off, f2 v) { *reinterpret_cast<f2*>(rec + lane * rs + off) = v; };
+        // invariant at the top of every bus: a B window is pending (before the first bus: an all-zero one)
+        static_for<0, PB::RS / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; putw(PB::RS, 2 * j, f2{0.f, 0.f}); });
+        gws_w2r();
+        for (int n = n0; n < n1; ++n) {
+          const long long ar = adj_row(n), rr = state_row(k, n);
+          const f4 a0 = *row_ptr(A.adj, ar, lane);
+          f4 xsum = *row_ptr(A.adj, ar + 1, lane);
+          const f4 s0 = *row_ptr(A.state, rr, lane);
+          f2 xs[XL];
+          f2 (&m)[D / 2] = reinterpret_cast<f2 (&)[D / 2]>(xs[2]);
+          f2 (&S)[H / 2] = reinterpret_cast<f2 (&)[H / 2]>(xs[SOFF]);
+          load_pairs<D>(A.state, rr + 1, lane, m);
+          f2 macc[D / 2];
+          load_pairs<D>(A.adj, ar + RM, lane, macc);
+          load_pairs<H>(A.msg, ((((long long)k * A.G + g) * N + n) * C::NPHI + fphi) * C::HQ, lane, S);
+          const int p0 = in_ptr[n], p1 = in_ptr[n + 1];
+          xs[0] = f2{s0.x, s0.y}; xs[1] = f2{s0.z, s0.w};
+          xs[XL - 1] = f2{(float)(p1 - p0), 1.f};
+          f2 gS[H / 2];
+          f2 a1[H / 2], a2[H / 2], g2[H / 2], g1[H / 2];
+          {   // recomputation of L' with the previous bus's B window draining behind it
+            auto dr = gw_drain<PB, 0>(baseB, ra, rb, accB);
+            dr.prologue();
+            mlp2_fwd<LIN, H>(PT + A.t_off[C::NPHI + l] + koff * A.t_sz[C::NPHI + l], xs, a1, a2, dr);
+            gws_r2w();
+          }
+          // output layer: g2 = (W4^T g3) * lrelu'(a2);  dW4 | db4 += g3 (x) [a2 | 1]   (not overlapped)
+          if constexpr (l == 2) {
+            bwd_rows<OUTP, H>(nb, macc, g2);
+          } else {
+            const f2 g3s[1] = {f2{l == 0 ? a0.y : (is_gen[n] ? 0.f : a0.x), 0.f}};
+            bwd_rows<2, H>(nb, g3s, g2);
+          }
+#pragma unroll
+          for (int u = 0; u < H / 2; ++u) g2[u] = g2[u] * dlrelu2(a2[u]);
+          static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putB(rec, lane, j, a2[j]); });
+          gws_putB(rec, lane, H / 2, f2{1.f, 0.f});
+          static_for<0, NA4>([&](auto t_) {
+            constexpr int t = decltype(t_)::value;
+            if constexpr (l == 2) {
+              static_for<0, 6>([&](auto j_) { constexpr int j = decltype(j_)::value; if constexpr (6 * t + j < D / 2) gws_putA(rec, lane, j, macc[6 * t + j]); });
+            } else {
+              gws_putA(rec, lane, 0, f2{l == 0 ? a0.y : (is_gen[n] ? 0.f : a0.x), 0.f});
+            }
+            gws_w2r(); gws_pass(rec, lane, T4[t]); gws_r2w();
+          });
+          // hidden layer
+          bwd_rows<H, H>(nb + NL::oW2, g2, g1);
+#pragma unroll
+          for (int u = 0; u < H / 2; ++u) g1[u] = g1[u] * dlrelu2(a1[u]);
+          // L window: dW2 | db2 and dW1 | db1 drain behind the input-adjoint stream (and the phi head of this bus)
+          static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; putw(PL::RS, 2 * j, g1[j]); putw(PL::RS, 48 + 2 * j, g2[j]); putw(PL::RS, 60 + 2 * j, a1[j]); });
+          putw(PL::RS, 60 + H, f2{1.f, 0.f});
+          static_for<0, XL>([&](auto j_) { constexpr int j = decltype(j_)::value; putw(PL::RS, 12 + 2 * j, xs[j]); });
+          gws_w2r();
+          constexpr int SG = 3 * (((LIN + 3) / 4 * H * 4 + 31) / 32);          // background slots of the input-adjoint stream
+          {
+            auto dr = gw_drain<PL, 0>(baseL, ra, rb, accL);
+            dr.prologue();
+            bwd_inputs<(LIN + 3) / 4, H>(nb + NL::total, g1, [&](auto ip_, f2 v) {
+              constexpr int ip = decltype(ip_)::value;
+              if constexpr (ip == 0) { xsum.x += v.x; xsum.y += v.y; }
+              else if constexpr (ip == 1) xsum.z += v.x;
+              else if constexpr (ip < SOFF) macc[ip - 2] += v;
+              else if constexpr (ip < SOFF + H / 2) gS[ip - SOFF] = v;
+            }, dr);
+          }
+          f2 G1[H / 2];
+#pragma unroll
+          for (int j = 0; j < H / 2; ++j) G1[j] = f2{0.f, 0.f};
+          if (p0 < p1) {
+            f2 uh[H / 2];
+            constexpr int SH = 3 * ((D * H + 31) / 32);                        // slots of the phi head
+            {
+              auto dr = gw_drain<PL, SG>(baseL, ra, rb, accL);
+              phi_head<D, H>(ptb, m, uh, dr);
+              dr.template rest<SH>();
+              gws_r2w();
+            }
+            constexpr int ST = 3 * ((TLay2<PIN, H>::total - D * H + 31) / 32), SB = 3 * ((H * H + 31) / 32);   // slots of a line's tail / hidden backward
+            auto edge_window = [&](const f2 (&xt)[3], const f2 (&ea1)[H / 2], const f2 (&eg1)[H / 2], const f2 (&eg2)[H / 2]) {
+              static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; putw(PE::RS, 2 * j, eg1[j]); putw(PE::RS, 20 + 2 * j, eg2[j]); putw(PE::RS, 32 + 2 * j, ea1[j]); });
+              putw(PE::RS, 12, xt[0]); putw(PE::RS, 14, xt[1]); putw(PE::RS, 16, f2{xt[2].x, 1.f}); putw(PE::RS, 18, f2{0.f, 0.f});
+              putw(PE::RS, 32 + H, f2{1.f, 0.f});
+              gws_w2r();
+            };
+            {   // first line: nothing is pending
+              const f4 ea = *row_ptr(IN, row_ein + 3LL * p0, lane), eb = *row_ptr(IN, row_ein + 3LL * p0 + 1, lane);
+              const f2 xt[3] = {f2{ea.x, ea.y}, f2{ea.z, ea.w}, f2{eb.x, 0.f}};
+              f2 ea1[H / 2], ea2[H / 2], eg2[H / 2], eg1[H / 2];
+              phi_tail<PIN, H, D>(ptb, uh, xt, ea1, ea2);
+#pragma unroll
+              for (int u = 0; u < H / 2; ++u) eg2[u] = gS[u] * dlrelu2(ea2[u]);
+              bwd_rows<H, H>(pnb, eg2, eg1);
+#pragma unroll
+              for (int u = 0; u < H / 2; ++u) { eg1[u] = eg1[u] * dlrelu2(ea1[u]); G1[u] += eg1[u]; }
+              edge_window(xt, ea1, eg1, eg2);
+            }
+            for (int p = p0 + 1; p < p1; ++p) {       // every further line drains its predecessor's window behind its own streams
+              const f4 ea = *row_ptr(IN, row_ein + 3LL * p, lane), eb = *row_ptr(IN, row_ein + 3LL * p + 1, lane);
+              const f2 xt[3] = {f2{ea.x, ea.y}, f2{ea.z, ea.w}, f2{eb.x, 0.f}};
+              f2 ea1[H / 2], ea2[H / 2], eg2[H / 2], eg1[H / 2];
+              auto dr0 = gw_drain<PE, 0>(baseE, ra, rb, accE);
+              dr0.prologue();
+              phi_tail<PIN, H, D>(ptb, uh, xt, ea1, ea2, dr0);
+#pragma unroll
+              for (int u = 0; u < H / 2; ++u) eg2[u] = gS[u] * dlrelu2(ea2[u]);
+              auto dr1 = gw_drain<PE, ST>(baseE, ra, rb, accE);
+              bwd_rows<H, H>(pnb, eg2, eg1, dr1);
+              dr1.template rest<SB>();
+              gws_r2w();
+#pragma unroll
+              for (int u = 0; u < H / 2; ++u) { eg1[u] = eg1[u] * dlrelu2(ea1[u]); G1[u] += eg1[u]; }
+              edge_window(xt, ea1, eg1, eg2);
+            }
+            {   // d/dm += W1[:, :d]^T G1 with the last line's window draining behind it
+              constexpr int SP = 3 * (((D + 3) / 4 * H * 4 + 31) / 32);
+              auto dr = gw_drain<PE, 0>(baseE, ra, rb, accE);
+              dr.prologue();
+              bwd_inputs<(D + 3) / 4, H>(pnb + NLay2<PIN, H>::total, G1, [&](auto ip_, f2 v) {
+                constexpr int ip = decltype(ip_)::value;
+                if constexpr (ip < D / 2) macc[ip] += v;
+              }, dr);
+              dr.template rest<SP>();
+              gws_r2w();
+            }
+          } else {
+            auto dr = gw_drain<PL, SG>(baseL, ra, rb, accL);
+            dr.template rest<0>();
+            gws_r2w();
+          }
+          // B window of this bus (G1 = 0 when no line ends here): drains behind the next bus's recomputation
+          static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; putw(PB::RS, 2 * j, G1[j]); });
+          putw(PB::RS, H, f2{0.f, 0.f});
+          static_for<0, D / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; putw(PB::RS, 12 + 2 * j, m[j]); });
+          gws_w2r();
+          *row_ptr(A.adj, ar + 1, lane) = xsum;
+          store_pairs<D>(A.adj, ar + RM, lane, macc);
+        }
+        {   // the last bus's B window
+          auto dr = gw_drain<PB, 0>(baseB, ra, rb, accB);
+          dr.prologue();
+          dr.template rest<0>();
+          gws_r2w();
+        }
+        {   // flush the family's tiles into the wave's slab
+          constexpr int ob1 = LIN * H, oW2 = ob1 + H, ob2 = oW2 + H * H, oW4 = ob2 + H, ob4 = oW4 + OUT * H;
+          float* lb_ = slab + A.g_off[C::NPHI + l] + koff * A.g_sz[C::NPHI + l];
+          static_for<0, NB1>([&](auto t_) { constexpr int t = decltype(t_)::value;
+            gws_flush(lane, T1[t], lb_, [&](int c, int il) { const int i = 16 * t + il; return c < H ? (i < LIN ? c * LIN + i : (i == LIN ? ob1 + c : -1)) : -1; }, first_store); });
+          gws_flush(lane, T2, lb_, [&](int c, int il) { return c < H ? (il < H ? oW2 + c * H + il : (il == H ? ob2 + c : -1)) : -1; }, first_store);
+          static_for<0, NA4>([&](auto t_) { constexpr int t = decltype(t_)::value;
+            gws_flush(lane, T4[t], lb_, [&](int c, int il) { const int j = 12 * t + c; return (c < 12 && j < OUT) ? (il < H ? oW4 + j * H + il : (il == H ? ob4 + j : -1)) : -1; }, first_store); });
+          constexpr int pb1 = PIN * H, pW2 = pb1 + H, pb2 = pW2 + H * H;
+          float* pb_ = slab + A.g_off[fphi] + koff * A.g_sz[fphi];
+          gws_flush(lane, TP1, pb_, [&](int c, int il) { return c < H ? (il < PIN - D ? c * PIN + D + il : (il == PIN - D ? pb1 + c : -1)) : -1; }, first_store);
+          gws_flush(lane, TP2, pb_, [&](int c, int il) { return c < H ? (il < H ? pW2 + c * H + il : (il == H ? pb2 + c : -1)) : -1; }, first_store);
+          static_for<0, NDM>([&](auto t_) { constexpr int t = decltype(t_)::value;
+            gws_flush(lane, TPm[t], pb_, [&](int c, int il) { const int i = 16 * t + il; return (c < H && i < D) ? c * PIN + i : -1; }, first_store); });
+        }
+        STAMP(5 + l)
+      });
+      } else
       if constexpr (V2) {
       static_for<0, 3>([&](auto o_) {
         constexpr int l = (decltype(o_)::value == 0) ? 2 : decltype(o_)::value - 1;   // L_m first: its upstream is mbar_{k+1} itself
@@ -605,18 +808,19 @@ __global__ void gns_unfold_kernel(const float* __restrict__ gf, const float* __r
   for (int e = threadIdx.x; e < rest; e += blockDim.x) dst[H * IN + e] += g[H * INF + e];
 }
 
-template <int D, int H, bool MULTI, bool MFMA, bool V2>
+template <int D, int H, bool MULTI, bool MFMA, int VAR>
 static int launch_backward_t(const GnsBwdArgs& A, int blocks, hipStream_t st) {
-  hipLaunchKernelGGL((gns_backward_kernel<D, H, MULTI, MFMA, V2>), dim3(blocks), dim3(GNS_BWD_THREADS), 0, st, A);
+  hipLaunchKernelGGL((gns_backward_kernel<D, H, MULTI, MFMA, VAR>), dim3(blocks), dim3(GNS_BWD_THREADS), 0, st, A);
   return hipGetLastError() == hipSuccess ? GNS_OK : GNS_ELAUNCH;
 }
 
 int gns_launch_backward(int d, int h, int multi, int mfma, int variant, const GnsBwdArgs& A, int blocks, hipStream_t st) {
 #define GNS_CASE(DD, HH)                                                                                      \
   if (d == DD && h == HH) {                                                                                   \
-    if (mfma && multi && variant == 2) return launch_backward_t<DD, HH, true, true, true>(A, blocks, st);     \
-    if (mfma) return multi ? launch_backward_t<DD, HH, true, true, false>(A, blocks, st) : launch_backward_t<DD, HH, false, true, false>(A, blocks, st);   \
-    return multi ? launch_backward_t<DD, HH, true, false, false>(A, blocks, st) : launch_backward_t<DD, HH, false, false, false>(A, blocks, st);          \
+    if (mfma && multi && variant == 3) return launch_backward_t<DD, HH, true, true, 3>(A, blocks, st);        \
+    if (mfma && multi && variant == 2) return launch_backward_t<DD, HH, true, true, 2>(A, blocks, st);        \
+    if (mfma) return multi ? launch_backward_t<DD, HH, true, true, 1>(A, blocks, st) : launch_backward_t<DD, HH, false, true, 1>(A, blocks, st);   \
+    return multi ? launch_backward_t<DD, HH, true, false, 1>(A, blocks, st) : launch_backward_t<DD, HH, false, false, 1>(A, blocks, st);          \
   }
   GNS_FOR_EACH_DIMS(GNS_CASE)
 #undef GNS_CASE

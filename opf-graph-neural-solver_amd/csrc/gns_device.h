@@ -41,8 +41,14 @@ __device__ __forceinline__ int opaque_zero() {
 // load is issued: touching one of its registers forces exactly that.
 __device__ __forceinline__ void touch(const f16v& v) { asm volatile("" ::"s"(v[0])); }
 
-template <int NF, class VP = cf16p, class F>
-__device__ __forceinline__ void stream_pairs(cfp p, F&& f) {
+// Background hook of a weight stream: slot<S>() is called three times per 32-float step (before packed FMAs 0, 5 and 10 of the
+// step), S = 3 * step + {0,1,2}.  The V3 backward issues one matrix-pipe instruction of a pending weight-gradient chain per
+// slot: a 16x16x4 fp32 MFMA occupies the matrix pipe for 32 cycles and the vector issue for 8, so one MFMA per ~6 packed FMAs
+// keeps both pipes busy from ONE wave (gns_dw.h, GwDrain).
+struct NoBG { template <int S> __device__ __forceinline__ void slot() {} };
+
+template <int NF, class VP = cf16p, class F, class BG = NoBG>
+__device__ __forceinline__ void stream_pairs(cfp p, F&& f, BG&& bg = BG{}) {
   // 32-float steps: two s_load_dwordx16 are in flight while the previous 32 floats feed 16 packed FMAs
   constexpr int NST = (NF + 31) / 32;
   p += opaque_zero();
@@ -69,6 +75,10 @@ __device__ __forceinline__ void stream_pairs(cfp p, F&& f) {
     static_for<0, 16>([&](auto t_) {
       constexpr int t = decltype(t_)::value;
       constexpr int w = c * 32 + 2 * t;
+      if constexpr (!std::is_same<std::decay_t<BG>, NoBG>::value && (t == 0 || t == 5 || t == 10)) {
+        bg.template slot<3 * c + t / 5>();
+        __builtin_amdgcn_sched_barrier(0);
+      }
       if constexpr (w < NF) {
         if constexpr (t < 8) f(std::integral_constant<int, w>{}, f2{c0[2 * t], c0[2 * t + 1]});
         else f(std::integral_constant<int, w>{}, f2{c1[2 * (t - 8)], c1[2 * (t - 8) + 1]});
@@ -183,10 +193,10 @@ struct TLay2 {
   static constexpr int ob1 = IN * H, oW2 = ob1 + H, ob2 = oW2 + H * H, total = ob2 + H;
 };
 
-template <int IN, int H>
-__device__ __forceinline__ void mlp2_fwd(cfp blk, const f2 (&x)[(IN + 1) / 2], f2 (&a1)[H / 2], f2 (&a2)[H / 2]) {
+template <int IN, int H, class BG = NoBG>
+__device__ __forceinline__ void mlp2_fwd(cfp blk, const f2 (&x)[(IN + 1) / 2], f2 (&a1)[H / 2], f2 (&a2)[H / 2], BG&& bg = BG{}) {
   using B = TLay2<IN, H>;
-  stream_pairs<B::total>(blk, [&](auto w_, f2 s) {
+  stream_pairs<B::total, cf16p>(blk, [&](auto w_, f2 s) {
     constexpr int w = decltype(w_)::value;
     if constexpr (w < B::ob1) {
       constexpr int i = w / H, j = (w % H) / 2;
@@ -203,7 +213,7 @@ __device__ __forceinline__ void mlp2_fwd(cfp blk, const f2 (&x)[(IN + 1) / 2], f
       constexpr int j = (w - B::ob2) / 2;
       a2[j] = lrelu2(a2[j] + s);
     }
-  });
+  }, bg);
   pin_all(a2);
 }
 
@@ -211,17 +221,17 @@ __device__ __forceinline__ void mlp2_fwd(cfp blk, const f2 (&x)[(IN + 1) / 2], f
 // rows of W1t - 200 of the 370 streamed floats - give the same partial sums u for all of them: phi_head once per bus,
 // phi_tail (the 5 line parameters, b1, layer 2) once per line.  The accumulation order is that of mlp2_fwd
 // (inputs 0..D-1, then D..IN-1, then the bias), so a1, a2 are bitwise the same.
-template <int D, int H>
-__device__ __forceinline__ void phi_head(cfp blk, const f2 (&m)[D / 2], f2 (&u)[H / 2]) {
-  stream_pairs<D * H>(blk, [&](auto w_, f2 s) {
+template <int D, int H, class BG = NoBG>
+__device__ __forceinline__ void phi_head(cfp blk, const f2 (&m)[D / 2], f2 (&u)[H / 2], BG&& bg = BG{}) {
+  stream_pairs<D * H, cf16p>(blk, [&](auto w_, f2 s) {
     constexpr int w = decltype(w_)::value, i = w / H, j = (w % H) / 2;
     const f2 xi = splat(lane_of<i>(m));
     u[j] = (i == 0) ? s * xi : __builtin_elementwise_fma(s, xi, u[j]);
-  });
+  }, bg);
   pin_all(u);
 }
-template <int IN, int H, int D>
-__device__ __forceinline__ void phi_tail(cfp blk, const f2 (&u)[H / 2], const f2 (&xt)[(IN - D + 1) / 2], f2 (&a1)[H / 2], f2 (&a2)[H / 2]) {
+template <int IN, int H, int D, class BG = NoBG>
+__device__ __forceinline__ void phi_tail(cfp blk, const f2 (&u)[H / 2], const f2 (&xt)[(IN - D + 1) / 2], f2 (&a1)[H / 2], f2 (&a2)[H / 2], BG&& bg = BG{}) {
   using B = TLay2<IN, H>;
   constexpr int W0 = D * H;
 #pragma unroll
@@ -243,7 +253,7 @@ __device__ __forceinline__ void phi_tail(cfp blk, const f2 (&u)[H / 2], const f2
       constexpr int j = (w - B::ob2) / 2;
       a2[j] = lrelu2(a2[j] + s);
     }
-  });
+  }, bg);
   pin_all(a2);
 }
 
@@ -283,20 +293,20 @@ __device__ __forceinline__ void mlp2_bwd(cfp blk, const f2 (&a1)[H / 2], const f
 
 // ---- layer-wise data path of the backward (used where each layer's weight gradient is contracted as soon as its operands exist) ----
 // gout[i] = sum_j Wn[j][i] gin[j] from an [NJ][H] stream (output layer and hidden layer of the data path)
-template <int NJP, int H>
-__device__ __forceinline__ void bwd_rows(cfp blk, const f2 (&gin)[NJP / 2], f2 (&gout)[H / 2]) {
-  stream_pairs<NJP * H>(blk, [&](auto w_, f2 s) {
+template <int NJP, int H, class BG = NoBG>
+__device__ __forceinline__ void bwd_rows(cfp blk, const f2 (&gin)[NJP / 2], f2 (&gout)[H / 2], BG&& bg = BG{}) {
+  stream_pairs<NJP * H, cf16p>(blk, [&](auto w_, f2 s) {
     constexpr int w = decltype(w_)::value, j = w / H, i = (w % H) / 2;
     const f2 gj = splat(lane_of<j>(gin));
     gout[i] = (j == 0) ? s * gj : __builtin_elementwise_fma(s, gj, gout[i]);
-  });
+  }, bg);
   pin_all(gout);
 }
 // Input adjoints from the input-major stream W1x[NG][H][4]: four inputs at a time, each finished pair handed to sink(ic<pair>, value)
-template <int NG, int H, class F>
-__device__ __forceinline__ void bwd_inputs(cfp blk, const f2 (&g1)[H / 2], F&& sink) {
+template <int NG, int H, class F, class BG = NoBG>
+__device__ __forceinline__ void bwd_inputs(cfp blk, const f2 (&g1)[H / 2], F&& sink, BG&& bg = BG{}) {
   f2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
-  stream_pairs<NG * H * 4>(blk, [&](auto w_, f2 s) {
+  stream_pairs<NG * H * 4, cf16p>(blk, [&](auto w_, f2 s) {
     constexpr int w = decltype(w_)::value, g = w / (4 * H), r = w % (4 * H), j = r / 4, half = (r % 4) / 2;
     const f2 gj = splat(lane_of<j>(g1));
     if constexpr (half == 0) acc0 = (j == 0) ? s * gj : __builtin_elementwise_fma(s, gj, acc0);
@@ -306,7 +316,7 @@ __device__ __forceinline__ void bwd_inputs(cfp blk, const f2 (&g1)[H / 2], F&& s
       sink(std::integral_constant<int, 2 * g>{}, acc0);
       sink(std::integral_constant<int, 2 * g + 1>{}, acc1);
     }
-  });
+  }, bg);
 }
 
 // float4-row addressing: [row][lane] with 16 B per lane -> every wave access is one contiguous 1 KiB

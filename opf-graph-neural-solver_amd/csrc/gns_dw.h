@@ -591,3 +591,62 @@ __device__ __forceinline__ void gws_stage(int lane, const f32x4& Dt, float* stag
   }
 }
 
+
+// ---- V3: weight-gradient chains drained in the background of the weight streams ---------------------------------------------
+// A window [64 rows][RS] stays in LDS while the wave runs its next packed-FMA blocks; each background slot of those blocks
+// (gns_device.h, stream_pairs) issues ONE MFMA of the window's chains (chains alternate, so consecutive MFMAs never wait for
+// each other) and reads the operands of the slot three ahead (= the next 32-float step, whose scalar-load wait also retires
+// these LDS reads).  A program P describes a window: RS, NCH chains with their A / B column offsets, LEN = 16 * NCH slots.
+template <class P, int START, class ACC>
+struct GwDrain {
+  const float* base;                 // rec + row-map of this lane (see LEngine) + (lane & 15)
+  float (&ra)[4];
+  float (&rb)[4];
+  ACC acc;                           // acc(ic<chain>) -> f32x4& accumulator tile of the chain
+  template <int G>
+  __device__ __forceinline__ void load() {
+    constexpr int kk = G / P::NCH, ch = G % P::NCH;
+    const float* b = base + (8 * (kk >> 1) + 2 * (kk & 1)) * P::RS;
+    ra[G & 3] = b[P::aoff(ch)];
+    rb[G & 3] = b[P::boff(ch)];
+  }
+  template <int S>
+  __device__ __forceinline__ void slot() {
+    constexpr int g = START + S;
+    if constexpr (g + 3 < P::LEN) load<g + 3>();
+    if constexpr (g < P::LEN) {
+      constexpr int ch = g % P::NCH;
+#ifndef GNS_ABLATE_PASS
+      f32x4& T = acc(std::integral_constant<int, ch>{});
+      T = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[g & 3], rb[g & 3], T, 0, 0, 0);
+#endif
+    }
+  }
+  // the first three slots' operands (call once after the window has been written and made visible)
+  __device__ __forceinline__ void prologue() { load<START>(); load<START + 1>(); load<START + 2>(); }
+  // issue whatever the streams did not get to (not overlapped with anything)
+  template <int FROM_S>
+  __device__ __forceinline__ void rest() {
+    static_for<FROM_S, (P::LEN > START ? P::LEN - START : 0)>([&](auto s_) { slot<decltype(s_)::value>(); });
+  }
+};
+template <class P, int START, class ACC>
+__device__ __forceinline__ GwDrain<P, START, ACC> gw_drain(const float* base, float (&ra)[4], float (&rb)[4], ACC acc) {
+  return GwDrain<P, START, ACC>{base, ra, rb, acc};
+}
+
+// window programs of the V3 lane-per-grid backward (all windows live in the wave's record buffer, one at a time):
+//   L  [g1 0..11 | x,1 12..47 | g2 48..59 | a1,1 60..71]                 chains: dW2, dW1 tile 0..NB1-1
+//   E  [g1 0..11 | line parameters,1 12..19 | g2 20..31 | a1,1 32..43]   chains: line columns of dW1 | db1, dW2 | db2
+//   B  [G1 0..11 | m 12..]                                               chains: latent columns of dW1, 16 at a time
+template <int NB1>
+struct GwProgL { static constexpr int RS = 76, NCH = 1 + NB1, LEN = 16 * NCH;
+                 static constexpr int aoff(int ch) { return ch == 0 ? 48 : 0; }
+                 static constexpr int boff(int ch) { return ch == 0 ? 60 : 12 + 16 * (ch - 1); } };
+struct GwProgE { static constexpr int RS = 44, NCH = 2, LEN = 32;
+                 static constexpr int aoff(int ch) { return ch == 0 ? 0 : 20; }
+                 static constexpr int boff(int ch) { return ch == 0 ? 12 : 32; } };
+template <int NDM>
+struct GwProgB { static constexpr int RS = 36, NCH = NDM, LEN = 16 * NDM;
+                 static constexpr int aoff(int) { return 0; }
+                 static constexpr int boff(int ch) { return 12 + 16 * ch; } };

@@ -64,15 +64,16 @@ def test_single_grid_2d_api_and_cpu_inputs(name):
     assert_close(tot, g['total_loss'][0], REL, what='total')
 
 
-@pytest.fixture(params=['matrix-pipe', 'matrix-pipe-wide-records', 'packed-fma'])
+@pytest.fixture(params=['matrix-pipe', 'matrix-pipe-background-chains', 'matrix-pipe-wide-records', 'packed-fma'])
 def dw_engine(request):
     """The weight-gradient paths of the lane-per-grid backward kernel (gns_set_option "dw_mfma", "bwd_variant"): matrix pipe
-    with the layer-wise sweep and sub-record windows (default), matrix pipe with wide half-wave records, packed-FMA tiles."""
+    with the layer-wise sweep and sub-record windows, the same with the contraction chains issued behind the weight streams,
+    matrix pipe with wide half-wave records, packed-FMA tiles."""
     import opf_graph_neural_solver_amd as amd
     old = amd.get_option('dw_mfma'), amd.get_option('bwd_variant'), amd.get_option('train_mapping')
     amd.set_option('train_mapping', 1)                 # (small batches would otherwise go to the grid-per-workgroup pair)
     amd.set_option('dw_mfma', 0 if request.param == 'packed-fma' else 1)
-    amd.set_option('bwd_variant', 1 if request.param == 'matrix-pipe-wide-records' else 2)
+    amd.set_option('bwd_variant', {'matrix-pipe-wide-records': 1, 'matrix-pipe-background-chains': 3}.get(request.param, 2))
     yield request.param
     amd.set_option('dw_mfma', old[0]); amd.set_option('bwd_variant', old[1]); amd.set_option('train_mapping', old[2])
 
