@@ -17,9 +17,17 @@ struct GnsTuning {
   int gw_ready;      // gns_gw_init_device() succeeded
   int train_mapping; // GNS_TRAIN_MAPPING: mapping of the training-mode forward + backward pair: 0 auto, 1 lane, 2 lds
   int bwd_variant;   // GNS_BWD_VARIANT: family sweep of the lane-per-grid backward: 1 wide half-wave records, 2 layer-wise + sub-record windows
+  int team;          // GNS_TEAM: workgroups per 64-grid group of the lane mapping when the batch leaves CUs idle: 0 auto, 1 none, 2, 4
+  int ncu;           // compute units of the device (teams must be resident all at once)
 };
 GnsTuning make_tuning() {
-  GnsTuning t{0, 0, GNS_FWD_THREADS / 64, 1, 1, 0, 0, 2};
+  GnsTuning t{0, 0, GNS_FWD_THREADS / 64, 1, 1, 0, 0, 2, 0, 0};
+  {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) t.ncu = n;
+    else (void)hipGetLastError();
+  }
+  if (const char* e = std::getenv("GNS_TEAM")) { const int v = std::atoi(e); if (v >= 0 && v <= GNS_MAX_TEAM) t.team = v; }
   if (const char* e = std::getenv("GNS_FWD_MAPPING")) t.fwd_mapping = !std::strcmp(e, "lane") ? 1 : (!std::strcmp(e, "lds") ? 2 : 0);
   if (const char* e = std::getenv("GNS_GW_PACK")) { const int p = std::atoi(e); if (p >= 1 && p <= 16) t.gw_pack = p; }
   if (const char* e = std::getenv("GNS_FWD_WAVES")) { const int w = std::atoi(e); if (gns_part_index(w) >= 0 && w * 64 <= GNS_FWD_MAX_THREADS) t.fwd_waves = w; }
@@ -47,6 +55,7 @@ extern "C" int gns_set_option(const char* name, int value) {
   if (!std::strcmp(name, "fwd_waves")) { if (gns_part_index(value) < 0 || value * 64 > GNS_FWD_MAX_THREADS) return GNS_EINVAL; t.fwd_waves = value; return GNS_OK; }
   if (!std::strcmp(name, "fwd_plane")) { t.fwd_plane = value ? 1 : 0; return GNS_OK; }
   if (!std::strcmp(name, "dw_mfma")) { t.dw_mfma = value ? 1 : 0; return GNS_OK; }
+  if (!std::strcmp(name, "team")) { if (value < 0 || value > GNS_MAX_TEAM) return GNS_EINVAL; t.team = value; return GNS_OK; }
   return GNS_EINVAL;
 }
 extern "C" int gns_get_option(const char* name, int* value) {
@@ -59,6 +68,7 @@ extern "C" int gns_get_option(const char* name, int* value) {
   else if (!std::strcmp(name, "fwd_waves")) *value = t.fwd_waves;
   else if (!std::strcmp(name, "fwd_plane")) *value = t.fwd_plane;
   else if (!std::strcmp(name, "dw_mfma")) *value = t.dw_mfma;
+  else if (!std::strcmp(name, "team")) *value = t.team;
   else return GNS_EINVAL;
   return GNS_OK;
 }
@@ -92,6 +102,16 @@ void prof_mark(int which, bool start, hipStream_t st) {
 }
 }  // namespace
 
+// Workgroups per 64-grid group of the lane-per-grid kernels (gns_device.h, "teams").  Asked by gns_workspace_bytes,
+// gns_forward and gns_backward alike.
+static int lane_team(int64_t Bt) {
+  const GnsTuning& T = tuning();
+  const int64_t groups = (Bt + GNS_LANES - 1) / GNS_LANES;
+  if (groups > GNS_TEAM_MAX_GROUPS) return 1;
+  const int ncu = T.ncu < GNS_BWD_MAX_WG ? T.ncu : GNS_BWD_MAX_WG;
+  return gns_team_size(groups, ncu, T.team);
+}
+
 // Which mapping runs a training-mode forward and its backward.  Evaluated identically by gns_forward and gns_backward:
 // changing "train_mapping" / "gw_pack" between a forward and its backward is a caller error.
 static int gw_train_pack(const gns_config* c, int64_t Bt) {
@@ -101,11 +121,12 @@ static int gw_train_pack(const gns_config* c, int64_t Bt) {
   if (!gns_gw_supported(c->n_bus, c->n_line, c->latent_dim, c->hidden_dim, c->multiple_phi, P)) return 0;
   if (!gns_gw_backward_supported(c->n_bus, c->n_line, c->latent_dim, c->hidden_dim, c->multiple_phi, P)) return 0;
   if (T.train_mapping == 2) return P;
-  // auto: the lane-per-grid pair needs one workgroup per 64 grids and ~256 of them to fill the chip; below ~6000 grids per
-  // GPU the grid-per-workgroup pair (one workgroup per grid) is the faster one (measured, case118 x 4096: 1.99 vs 3.17 ms);
-  // above, the lane-per-grid backward wins (its weight streams are re-used across the buses of 64 grids).
+  // auto: below ~2000 grids per GPU (case118; ~1000 for case300) the grid-per-workgroup pair, one workgroup per grid, is the
+  // faster one (measured, case118 x 1024: 0.55 vs 1.20 ms); above, the lane-per-grid pair - teams of workgroups per 64-grid
+  // group keep the chip busy down to a quarter of its CUs in groups (case118 x 4096: 1.38 vs 1.96 ms, x 8192: 2.31 vs 3.86).
   const int64_t groups = (Bt + GNS_LANES - 1) / GNS_LANES;
-  return (groups <= 96 && gns_gw_backward_wpg(c->n_bus) <= 2) ? P : 0;
+  const int wpg = gns_gw_backward_wpg(c->n_bus);
+  return groups <= 32 / (wpg > 2 ? wpg / 2 : 1) ? P : 0;
 }
 // Grids per workgroup of the evaluation-mode forward when it runs on the grid-per-workgroup kernel, 0 when the lane-per-grid
 // kernel runs it.  gns_workspace_bytes, gns_forward and gns_uses_packed_inputs must agree, so they all ask here.
@@ -212,7 +233,7 @@ extern "C" int gns_workspace_bytes(const gns_config* cfg, int64_t Bt, int save_s
   if (fwd_bytes) *fwd_bytes = L.total;
   if (bwd_bytes) {
     GnsBwdLayout B;
-    gns_bwd_layout(cfg->n_bus, cfg->n_line, cfg->latent_dim, cfg->hidden_dim, cfg->K, cfg->multiple_phi, Bt, &B);
+    gns_bwd_layout(cfg->n_bus, cfg->n_line, cfg->latent_dim, cfg->hidden_dim, cfg->K, cfg->multiple_phi, Bt, lane_team(Bt), &B);
     *bwd_bytes = B.total;
   }
   return GNS_OK;
@@ -316,9 +337,13 @@ extern "C" int gns_forward(const gns_config* cfg, const void* topo_dev, const fl
   for (int i = 0; i < fam.nfam; ++i) { A.t_off[i] = fam.t_off[i]; A.t_sz[i] = fam.t_sz[i]; }
   for (int k = 0; k < K; ++k) A.gw[k] = (float)std::pow((double)cfg->gamma, (double)(K - k));   // main.py:198
   A.Bt = Bt; A.G = L.groups; A.N = N; A.E = E; A.K = K; A.save = save_state ? 1 : 0;
-  const int waves = T.fwd_waves;
-  A.part_idx = gns_part_index(waves);
+  A.team = lane_team(Bt);
+  A.team_ws = (unsigned char*)(ws + L.off_team);
+  int waves = T.fwd_waves;
+  while (waves * A.team > GNS_MAXP) waves /= 2;
+  A.part_idx = gns_part_index(waves * A.team);
   A.plane = ((size_t)N * GNS_LANES * 2 * sizeof(float) <= (size_t)GNS_PLANE_MAX_BYTES && T.fwd_plane) ? 1 : 0;
+  if (A.team > 1 && hipMemsetAsync(A.team_ws, 0, (size_t)L.groups * GNS_TEAM_CTR_BYTES, st) != hipSuccess) return GNS_ELAUNCH;
   prof_mark(0, true, st);
   rc = gns_launch_forward(d, h, cfg->multiple_phi, A, waves * 64, st);
   prof_mark(0, false, st);
@@ -370,13 +395,14 @@ extern "C" int gns_backward(const gns_config* cfg, const void* topo_dev, const f
   GnsFwdLayout L;
   gns_fwd_layout(N, E, d, h, K, cfg->multiple_phi, Bt, 1, &L);
   GnsBwdLayout B;
-  gns_bwd_layout(N, E, d, h, K, cfg->multiple_phi, Bt, &B);
+  const int team = lane_team(Bt);
+  gns_bwd_layout(N, E, d, h, K, cfg->multiple_phi, Bt, team, &B);
   if (fwd_workspace_bytes < L.total || bwd_workspace_bytes < B.total) return GNS_ESIZE;
   GnsFamilies fam; gns_families(d, h, K, cfg->multiple_phi, &fam);
   hipStream_t st = (hipStream_t)stream;
   const char* fw = (const char*)fwd_workspace;
   char* bw = (char*)bwd_workspace;
-  const int blocks = (int)(B.groups < GNS_BWD_MAX_WG ? B.groups : GNS_BWD_MAX_WG);
+  const int blocks = (int)(B.groups * team < GNS_BWD_MAX_WG ? B.groups * team : GNS_BWD_MAX_WG);
   const long long nslab = (long long)blocks * GNS_BWD_WAVES;
   // the V2 sweep writes every slab entry itself on a workgroup's first group: no 90 MB memset in front of it
   const bool v2 = tuning().dw_mfma && tuning().bwd_variant >= 2 && cfg->multiple_phi;
@@ -395,7 +421,9 @@ extern "C" int gns_backward(const gns_config* cfg, const void* topo_dev, const f
   }
   for (int k = 0; k < K; ++k) A.gw[k] = (float)std::pow((double)cfg->gamma, (double)(K - k));
   A.Bt = Bt; A.G = B.groups; A.slab_floats = B.slab_floats; A.N = N; A.E = E; A.K = K;
-  A.part_idx = gns_part_index(GNS_BWD_WAVES);
+  A.part_idx = gns_part_index(GNS_BWD_WAVES * team);
+  A.team = team; A.team_ws = (unsigned char*)(bw + B.off_team);
+  if (team > 1 && hipMemsetAsync(A.team_ws, 0, (size_t)B.groups * GNS_TEAM_CTR_BYTES, st) != hipSuccess) return GNS_ELAUNCH;
   A.slab_dirty = v2 ? 1 : 0;
   prof_mark(1, true, st);
   // The weight-gradient contraction over the grids runs on the matrix pipe (exact fp32) unless GNS_DW_MFMA=0 asks for

@@ -40,10 +40,18 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
             in_a = topo + topo[TH_IN_A], in_b = topo + topo[TH_IN_B], out_ptr = topo + topo[TH_OUT_PTR],
             out_c = topo + topo[TH_OUT_C], out_d = topo + topo[TH_OUT_D], is_gen = topo + topo[TH_IS_GEN],
             p2q = topo + topo[TH_P2Q], q2p = topo + topo[TH_Q2P], incd_ptr = topo + topo[TH_INCD_PTR],
-            incd = topo + topo[TH_INCD], part = topo + topo[TH_PART] + A.part_idx * (GNS_MAXW + 1),
-            epart = topo + topo[TH_EPART] + A.part_idx * (GNS_MAXW + 1);
-  const int n0 = part[wave], n1 = part[wave + 1];
-  const int e0 = epart[wave], e1 = epart[wave + 1];
+            incd = topo + topo[TH_INCD], part = topo + topo[TH_PART] + A.part_idx * (GNS_MAXP + 1),
+            epart = topo + topo[TH_EPART] + A.part_idx * (GNS_MAXP + 1);
+  // team of A.team workgroups per 64-grid group (gns_device.h, "teams"); blocks 8 apart share an XCD when the count allows it
+  const int tsize = A.team, nteams = gridDim.x / tsize;
+  int team_id = blockIdx.x, member = 0;
+  if (tsize > 1) {
+    if ((nteams & 7) == 0) { team_id = (blockIdx.x / (8 * tsize)) * 8 + (blockIdx.x & 7); member = (blockIdx.x >> 3) % tsize; }
+    else { team_id = blockIdx.x / tsize; member = blockIdx.x % tsize; }
+  }
+  const int cw = member * W + wave, tw = tsize * W;
+  const int n0 = part[cw], n1 = part[cw + 1];
+  const int e0 = epart[cw], e1 = epart[cw + 1];
   const long long R = gns_in_rows(N, E);
   const float* IN = A.in;
 
@@ -52,6 +60,12 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
                                      2 * GNS_REC_ROWS * RecLay2<C::PHI_IN, H>::RS) + 32;   // +32: the MFMA variant reads 16-wide column blocks
   __shared__ __attribute__((aligned(16))) float rec_all[W][RECF];
   __shared__ float red[2][W][GNS_LANES];
+  __shared__ int team_failed;
+  if (threadIdx.x == 0) team_failed = 0;
+  GnsTeam team;
+  team.size = tsize; team.member = member; team.epoch = 0; team.failed = &team_failed;
+  __syncthreads();                                   // team_failed is initialised
+  team_setup(team, reinterpret_cast<unsigned*>(A.team_ws + (long long)team_id * GNS_TEAM_CTR_BYTES));
   float* rec = rec_all[wave];
   float* slab = A.slab + ((long long)blockIdx.x * W + wave) * A.slab_floats;
   const float invN = 1.0f / (float)N;
@@ -71,8 +85,11 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
       for (int i = lane; i < (int)A.g_sz[2]; i += 64) z1[i] = 0.f;
     }
   }
-  for (long long g = blockIdx.x; g < A.G; g += gridDim.x) {
-    const bool first_store = V2 && A.slab_dirty && g == (long long)blockIdx.x;
+  for (long long g = team_id; g < A.G; g += nteams) {
+    const bool first_store = V2 && A.slab_dirty && g == (long long)team_id;
+    team.epoch = 0;
+    team.ctr = reinterpret_cast<unsigned*>(A.team_ws + g * GNS_TEAM_CTR_BYTES);
+    team.red = reinterpret_cast<float*>(A.team_ws + A.G * GNS_TEAM_CTR_BYTES) + g * GNS_TEAM_RED_FLOATS;
     const long long in_base = g * R, row_ein = in_base + 3LL * N, row_eout = row_ein + 3LL * E, row_grid = row_eout + E;
     const long long b = g * GNS_LANES + lane;
     const bool live = b < A.Bt;
@@ -144,12 +161,17 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
         }
       }
       STAMP(0)
-      red[k & 1][wave][lane] = lb;
-      __syncthreads();
+      if (tsize == 1) red[k & 1][wave][lane] = lb;
+      else team.red[((k & 1) * GNS_MAXP + cw) * GNS_LANES + lane] = lb;
+      team_barrier(team);
       STAMP(1)
       float lbar = 0.f;
+      if (tsize == 1) {
 #pragma unroll
-      for (int w = 0; w < W; ++w) lbar += red[k & 1][w][lane];
+        for (int w = 0; w < W; ++w) lbar += red[k & 1][w][lane];
+      } else {
+        for (int w = 0; w < tw; ++w) lbar += team.red[((k & 1) * GNS_MAXP + w) * GNS_LANES + lane];
+      }
       const float pgbar = lbar / (low1 ? 2.f * (gsum.y - gsum.z) : 2.f * (gsum.w - gsum.y));   // d lambda / d p_global (main.py:47-51)
 
       // ---------------- Pb-edge ----------------
@@ -212,7 +234,7 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
         if (p + 1 < e1) edge_adjoint(p + 1, L1);
       }
       STAMP(2)
-      __syncthreads();
+      team_barrier(team);
       STAMP(3)
 
       // ---------------- Ub, pass G: every bus completes d/d(v,theta)_{k+1} from the per-line adjoints --------------
@@ -734,8 +756,9 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
       }   // !V2
       STAMP(8)
     }
-    __syncthreads();
+    team_barrier(team);
   }
+  if (team_failed && lane == 0) slab[0] = __builtin_nanf("");          // a team barrier gave up: the gradients must not look valid
 #ifdef GNS_STAMPS
   if (lane == 0) for (int i = 0; i < 10; ++i) A.slots[((long long)blockIdx.x * W + wave) * 10 + i] = (float)tph[i];   // diagnostic build only: slots are dead by now
 #endif

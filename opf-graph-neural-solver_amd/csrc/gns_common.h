@@ -18,8 +18,10 @@
 
 #define GNS_LANES 64
 #define GNS_TOPO_MAGIC 0x474e5331  // "GNS1"
-#define GNS_NPART 5                // bus partitions are stored for 1,2,4,8,16 waves per workgroup
-#define GNS_MAXW 16
+#define GNS_NPART 6                // bus partitions are stored for 1,2,4,8,16,32 waves per 64-grid group
+#define GNS_MAXW 16                // waves of ONE workgroup (sizes the LDS reduction buffers)
+#define GNS_MAXP 32                // waves of one 64-grid group: up to GNS_MAX_TEAM workgroups share a group (gns_device.h, "teams")
+#define GNS_MAX_TEAM 4
 
 // ---- topology blob: int32 words; hdr[i] below are word offsets from the blob start ----------------
 enum {
@@ -37,15 +39,15 @@ enum {
   TH_IS_GEN,    // [N]   1 if a generator sits on the bus (main.py:184-185)
   TH_GEN_PTR,   // [N+1] generators per bus, in generator order
   TH_GEN_IDX,   // [Gn]
-  TH_PART,      // [GNS_NPART][GNS_MAXW+1] bus ranges per wave, balanced by work
+  TH_PART,      // [GNS_NPART][GNS_MAXP+1] bus ranges per wave, balanced by work
   TH_P2Q,       // [E]   position in the source-sorted list of in-edge p
   TH_Q2P,       // [E]
-  TH_EPART,     // [GNS_NPART][GNS_MAXW+1] ranges of in-edge positions per wave (backward, edge-centric)
+  TH_EPART,     // [GNS_NPART][GNS_MAXP+1] ranges of in-edge positions per wave (backward, edge-centric)
   TH_INCD_PTR,  // [N+1] incidence list of the delta adjoints (backward)
   TH_INCD,      // [4E]  p*4 + code ; code 0:+dbar 1:-dbar 2:+dbar' 3:-dbar'
   TH_IN_DST,    // [E]   t = dst[e] of in-edge p
-  TH_UPART,     // [GNS_NPART][GNS_MAXW+1] forward update phase: ranges of units u = grp*N + n (grp 0: theta+v, 1: m), balanced by work
-  TH_PPART,     // [GNS_NPART][GNS_MAXW+1] forward physics phase: bus ranges balanced by incident lines
+  TH_UPART,     // [GNS_NPART][GNS_MAXP+1] forward update phase: ranges of units u = grp*N + n (grp 0: theta+v, 1: m), balanced by work
+  TH_PPART,     // [GNS_NPART][GNS_MAXP+1] forward physics phase: bus ranges balanced by incident lines
   TH_LANE_BUS,  // [N]   grid-per-workgroup mapping: bus handled by bus lane i (buses in descending in-degree order, so the
                 //       lanes of one wave run similar trip counts in their incidence loops)
   TH_TOTAL,     // blob length in words
@@ -60,8 +62,22 @@ enum {
 GNS_HD static inline int64_t gns_in_rows(int N, int E) { return 3LL * N + 4LL * E + 1; }
 
 static inline int gns_part_index(int waves) {
-  switch (waves) { case 1: return 0; case 2: return 1; case 4: return 2; case 8: return 3; case 16: return 4; default: return -1; }
+  switch (waves) { case 1: return 0; case 2: return 1; case 4: return 2; case 8: return 3; case 16: return 4; case 32: return 5; default: return -1; }
 }
+
+// "Teams": when a batch has fewer 64-grid groups than the chip has CUs, up to GNS_MAX_TEAM workgroups (on different CUs) share
+// one group - their waves split its buses exactly as the waves of one workgroup do, meet at team barriers (a counter in HBM,
+// agent-scope fences) and add their partial sums through a small HBM buffer.  `want` 0 = as many as fill `ncu` CUs.
+static inline int gns_team_size(int64_t groups, int ncu, int want) {
+  int c = 1;
+  while (c < GNS_MAX_TEAM && groups * (c * 2) <= ncu) c *= 2;      // every workgroup of every team must be resident at once
+  if (want > 0 && want < c) { c = 1; while (c * 2 <= want) c *= 2; }
+  return c;
+}
+// per group: one 64-byte line holding the arrival counter + the partial sums [2 parities][GNS_MAXP waves][64 lanes][2]
+#define GNS_TEAM_CTR_BYTES 64
+#define GNS_TEAM_RED_FLOATS (2 * GNS_MAXP * GNS_LANES * 2)
+static inline size_t gns_team_bytes(int64_t groups) { return (size_t)groups * (GNS_TEAM_CTR_BYTES + (size_t)GNS_TEAM_RED_FLOATS * 4); }
 
 // Parameter block geometry ------------------------------------------------------------------------
 // flat (state_dict) block of one LearningBlock: W1[h][in] b1[h] W2[h][h] b2[h] W4[out][h] b4[out]
@@ -135,8 +151,9 @@ struct GnsFwdLayout {
   int64_t mq;            // float4 rows holding the latent vector: ceil(d/4)
   int64_t rows_bus;      // 1 + mq
   int64_t slots;         // K+1 when the state is saved for backward, else 2
-  size_t off_pt, off_pn, off_in, off_lam, off_state, off_msg, total;
+  size_t off_pt, off_pn, off_in, off_lam, off_state, off_msg, off_team, total;
 };
+#define GNS_TEAM_MAX_GROUPS 128   // teams only form when every group can have two CUs
 
 static inline size_t gns_align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -154,6 +171,7 @@ static inline void gns_fwd_layout(int N, int E, int d, int h, int K, int multi, 
   L->off_state = o; o = gns_align256(o + (size_t)L->slots * L->groups * N * L->rows_bus * GNS_LANES * 16);
   // hidden-vector sums per (step, bus, phi family): saved by the training forward so that the backward need not recompute them
   L->off_msg = o;   o = gns_align256(o + (save ? (size_t)K * L->groups * N * (multi ? 3 : 1) * ((h + 3) / 4) * GNS_LANES * 16 : 0));
+  L->off_team = o;  o = gns_align256(o + (L->groups <= GNS_TEAM_MAX_GROUPS ? gns_team_bytes(L->groups) : 0));   // counters | partial sums
   L->total = o;
 }
 
@@ -165,18 +183,18 @@ struct GnsBwdLayout {
   int64_t slab_floats;     // per-wave gradient slab: one float per FOLDED parameter
   int64_t adj_rows;        // adjoint rows per bus
   int64_t nslab;           // number of slabs (workgroups x waves)
-  size_t off_adj, off_slots, off_slab, off_part, off_tmp, total;
+  size_t off_adj, off_slots, off_slab, off_part, off_tmp, off_team, total;
 };
 #define GNS_BWD_MAX_WG 256   // persistent backward workgroups (each loops over grid groups)
 
-static inline void gns_bwd_layout(int N, int E, int d, int h, int K, int multi, int64_t Bt, GnsBwdLayout* B) {
+static inline void gns_bwd_layout(int N, int E, int d, int h, int K, int multi, int64_t Bt, int team, GnsBwdLayout* B) {
   GnsFamilies f; gns_families(d, h, K, multi, &f);
   B->groups = (Bt + GNS_LANES - 1) / GNS_LANES;
   B->mq = (d + 3) / 4;
   B->rows_bus = 1 + B->mq;
   B->slab_floats = (f.g_total + 63) / 64 * 64;
   B->adj_rows = B->rows_bus + 1 + (multi ? 0 : (h + 3) / 4);   // (vbar,thbar,dpbar,-) | input adjoints | [hidden-sum adjoint, single phi] | mbar
-  int64_t wg = B->groups < GNS_BWD_MAX_WG ? B->groups : GNS_BWD_MAX_WG;
+  int64_t wg = B->groups * team < GNS_BWD_MAX_WG ? B->groups * team : GNS_BWD_MAX_WG;   // team > 1 only when groups * team fits
   B->nslab = wg * GNS_BWD_WAVES;
   size_t o = 0;
   B->off_adj = o;   o = gns_align256(o + (size_t)B->groups * N * B->adj_rows * GNS_LANES * 16);
@@ -184,5 +202,6 @@ static inline void gns_bwd_layout(int N, int E, int d, int h, int K, int multi, 
   B->off_slab = o;  o = gns_align256(o + (size_t)B->nslab * B->slab_floats * 4);
   B->off_part = o;  o = gns_align256(o + (size_t)GNS_RED_PARTS * B->slab_floats * 4);
   B->off_tmp = o;   o = gns_align256(o + (size_t)B->slab_floats * 4);
+  B->off_team = o;  o = gns_align256(o + (team > 1 ? gns_team_bytes(B->groups) : 0));
   B->total = o;
 }

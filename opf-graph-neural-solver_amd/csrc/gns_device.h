@@ -14,6 +14,71 @@ typedef const __attribute__((address_space(4))) f16v* cf16p;
 typedef f16v f16u __attribute__((aligned(4)));                       // a 16-float chunk that starts at any dword
 typedef const __attribute__((address_space(4))) f16u* cf16up;
 
+// ---- teams: several workgroups (on different CUs) working the buses of ONE 64-grid group ---------------------------------
+// Everything the waves of a group exchange already travels through HBM rows (state, adjoints, per-line slots), so a team needs
+// only (1) a barrier across its workgroups and (2) the per-wave partial sums in HBM instead of LDS.  The barrier is an arrival
+// counter (one per group, zero at launch, never reset: barrier b is passed when it reaches b * size); thread 0 of each
+// workgroup adds 1 and polls.  Around it the team's stores must become visible to the other members:
+//   * members on the SAME XCD share its L2, and the vector L1 is write-through: waiting for the stores (s_waitcnt vmcnt(0))
+//     releases them, dropping the own L1 lines (buffer_inv sc0) acquires - a few microseconds;
+//   * members on different XCDs need the agent-scope fences (L2 write-back + invalidate), ~170 us per barrier measured.
+// Workgroups are dealt to the XCDs round-robin, so the kernels place a team on blocks 8 apart - and CHECK it: team_setup
+// exchanges the XCC ids through a full-fence barrier and only a team that really shares an XCD takes the light path.
+// All workgroups of all teams are resident at once (gns_team_size caps groups * size at the CU count), so the poll always
+// ends; the poll count is bounded all the same - a wave that gives up marks the team failed (NaN losses / gradients, loud)
+// instead of hanging the device.
+struct GnsTeam {
+  unsigned* ctr;          // arrival counter of the group being worked
+  float* red;             // [2 parities][GNS_MAXP][64][2] partial sums of this group
+  int size, member;       // workgroups in the team, this workgroup's rank
+  unsigned epoch;         // barriers passed on ctr
+  int* failed;            // LDS word shared by the workgroup
+  bool local;             // every member runs on the same XCD
+};
+#define GNS_TEAM_POLL_LIMIT (1u << 22)
+__device__ __forceinline__ void team_arrive_and_wait(GnsTeam& t, unsigned* ctr, unsigned target) {
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // a failed workgroup still arrives: its partners move on
+    unsigned polls = 0;
+    while (!*t.failed && __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++polls > GNS_TEAM_POLL_LIMIT) { *t.failed = 1; break; }
+    }
+  }
+}
+__device__ __forceinline__ void team_barrier(GnsTeam& t) {
+  if (t.size == 1) { __syncthreads(); return; }
+  t.epoch += 1;
+  if (t.local) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this wave's stores have reached the shared L2
+    __syncthreads();
+    team_arrive_and_wait(t, t.ctr, t.epoch * (unsigned)t.size);
+    __syncthreads();
+    asm volatile("buffer_inv sc0" ::: "memory");                     // forget what the vector L1 held of the partners' rows
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    team_arrive_and_wait(t, t.ctr, t.epoch * (unsigned)t.size);
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+}
+// Once per kernel, on the 64-byte line of the team's first group: word 1 = setup counter, words 4.. = XCC id of each member.
+__device__ __forceinline__ void team_setup(GnsTeam& t, unsigned* line) {
+  t.local = false;
+  if (t.size == 1) return;
+  const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf;     // HW_REG_XCC_ID[3:0]
+  if (threadIdx.x == 0) __hip_atomic_store(line + 4 + t.member, xcc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  team_arrive_and_wait(t, line + 1, (unsigned)t.size);
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  bool same = true;
+  for (int m = 0; m < t.size; ++m) same = same && (__hip_atomic_load(line + 4 + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == xcc + 1);
+  t.local = same;
+}
+
 #define GNS_LEAKY 0.01f   // torch.nn.LeakyReLU default slope (GNS/main.py:23)
 
 template <int I, int N, class F>

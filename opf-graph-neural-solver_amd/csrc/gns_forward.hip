@@ -173,18 +173,26 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nwaves = blockDim.x >> 6;
-  const long long g = blockIdx.x;
+  // team of A.team workgroups per 64-grid group (gns_device.h): blocks 8 apart share an XCD (and its L2) when the groups allow it
+  const int tsize = A.team;
+  long long g = blockIdx.x;
+  int member = 0;
+  if (tsize > 1) {
+    if ((A.G & 7) == 0) { g = (long long)(blockIdx.x / (8 * tsize)) * 8 + (blockIdx.x & 7); member = (blockIdx.x >> 3) % tsize; }
+    else { g = blockIdx.x / tsize; member = blockIdx.x % tsize; }
+  }
+  const int cw = member * nwaves + wave, tw = tsize * nwaves;       // this wave among the waves of the group
   const int N = A.N, E = A.E, K = A.K;
   cip topo = (cip)A.topo;
   cfp PT = (cfp)A.pt;
   const cip in_ptr = topo + topo[TH_IN_PTR], in_src = topo + topo[TH_IN_SRC], in_a = topo + topo[TH_IN_A],
             in_b = topo + topo[TH_IN_B], out_ptr = topo + topo[TH_OUT_PTR], out_dst = topo + topo[TH_OUT_DST],
             out_c = topo + topo[TH_OUT_C], out_d = topo + topo[TH_OUT_D], is_gen = topo + topo[TH_IS_GEN],
-            part = topo + topo[TH_PART] + A.part_idx * (GNS_MAXW + 1);
-  const int n0 = part[wave], n1 = part[wave + 1];
-  const cip upart = topo + topo[TH_UPART] + A.part_idx * (GNS_MAXW + 1), ppart = topo + topo[TH_PPART] + A.part_idx * (GNS_MAXW + 1);
-  const int u0 = upart[wave], u1 = upart[wave + 1];       // (family group, bus) units of the update phase, group-major
-  const int q0w = ppart[wave], q1w = ppart[wave + 1];     // buses of the physics phase
+            part = topo + topo[TH_PART] + A.part_idx * (GNS_MAXP + 1);
+  const int n0 = part[cw], n1 = part[cw + 1];
+  const cip upart = topo + topo[TH_UPART] + A.part_idx * (GNS_MAXP + 1), ppart = topo + topo[TH_PPART] + A.part_idx * (GNS_MAXP + 1);
+  const int u0 = upart[cw], u1 = upart[cw + 1];           // (family group, bus) units of the update phase, group-major
+  const int q0w = ppart[cw], q1w = ppart[cw + 1];         // buses of the physics phase
   const long long R = gns_in_rows(N, E);
   const float* IN = A.in;
   const long long in_base = g * R;
@@ -196,7 +204,25 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
   // (v, theta) of every bus of the 64 grids for the step being produced, written by the update phase and gathered by
   // the line physics (6 neighbour buses per line): 60 KB for case118 instead of ~19 HBM rows per bus and step.
   __shared__ int unit_ctr[2];                        // evaluation mode: work queue of the update phase, one counter per step parity
+  __shared__ int team_failed;
   if (threadIdx.x < 2) unit_ctr[threadIdx.x] = 0;
+  if (threadIdx.x == 0) team_failed = 0;
+  GnsTeam team;
+  team.size = tsize; team.member = member; team.epoch = 0; team.failed = &team_failed;
+  team.ctr = reinterpret_cast<unsigned*>(A.team_ws + g * GNS_TEAM_CTR_BYTES);
+  team.red = reinterpret_cast<float*>(A.team_ws + A.G * GNS_TEAM_CTR_BYTES) + g * GNS_TEAM_RED_FLOATS;
+  __syncthreads();                                   // team_failed is initialised
+  team_setup(team, team.ctr);
+  // per-wave partial sums: LDS inside one workgroup, the group's HBM buffer across a team
+  auto red_put = [&](int par, float a, float c) {
+    if (tsize == 1) { red[par][wave][lane][0] = a; red[par][wave][lane][1] = c; }
+    else reinterpret_cast<f2*>(team.red)[(par * GNS_MAXP + cw) * GNS_LANES + lane] = f2{a, c};
+  };
+  auto red_sum = [&](int par, float& a, float& c) {
+    a = 0.f; c = 0.f;
+    if (tsize == 1) { for (int w = 0; w < nwaves; ++w) { a += red[par][w][lane][0]; c += red[par][w][lane][1]; } }
+    else for (int w = 0; w < tw; ++w) { const f2 r = reinterpret_cast<const f2*>(team.red)[(par * GNS_MAXP + w) * GNS_LANES + lane]; a += r.x; c += r.y; }
+  };
   extern __shared__ __attribute__((aligned(16))) unsigned char gns_dyn_lds[];
   f2* plane = reinterpret_cast<f2*>(gns_dyn_lds);
   const bool use_plane = A.plane != 0;
@@ -211,7 +237,7 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
 #pragma unroll
     for (int q = 0; q < MQ; ++q) *row_ptr(A.state, r0 + 1 + q, lane) = f4{0.f, 0.f, 0.f, 0.f};
   }
-  __syncthreads();                                  // the update phase reads buses initialised by other waves
+  team_barrier(team);                               // the update phase reads buses initialised by other waves
   const f4 gsum = *row_ptr(IN, row_grid, lane);     // (sumPd, sumPset, sumPmin, sumPmax)
   float tot_part = 0.f, last_part = 0.f;
   const float invN = 1.0f / (float)N;
@@ -310,7 +336,7 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
     // unit writes only its own bus and nothing is summed across units here, so which wave runs a unit cannot change
     // a bit of the result.  Training mode keeps the fixed ranges: with the state / hidden-sum saves in flight the
     // drawn order measured 4 % slower.
-    const bool draw = A.save == 0;
+    const bool draw = A.save == 0 && tsize == 1;
     for (int u = u0;;) {
       if (draw) {
         int t = 0;
@@ -324,7 +350,14 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
       ++u;
     }
     FSTAMP(0)
-    __syncthreads();   // every bus of the 64 grids now has v_{k+1}, theta_{k+1}
+    team_barrier(team);   // every bus of the 64 grids now has v_{k+1}, theta_{k+1}
+    if (use_plane && tsize > 1) {                          // a team member produced only its share of the plane: fetch all of it (N KB from L2)
+      for (int n = wave; n < N; n += nwaves) {
+        const f4 r = *row_ptr(A.state, state_row(ws, n), lane);
+        plane[n * GNS_LANES + lane] = f2{r.x, r.y};
+      }
+      __syncthreads();
+    }
     if (threadIdx.x == 0) unit_ctr[(k + 1) & 1] = 0;      // idle since the previous step; next drawn from two barriers from here
     FSTAMP(1)
 
@@ -387,12 +420,11 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
       *row_ptr(A.state, wr, lane) = f4{vn, thn, dp_pre, dq};
     }
     FSTAMP(2)
-    red[k & 1][wave][lane][0] = joule;
-    red[k & 1][wave][lane][1] = v2gs;
-    __syncthreads();
+    red_put(k & 1, joule, v2gs);
+    team_barrier(team);
     FSTAMP(3)
-    float jsum = 0.f, vsum = 0.f;
-    for (int w = 0; w < nwaves; ++w) { jsum += red[k & 1][w][lane][0]; vsum += red[k & 1][w][lane][1]; }
+    float jsum, vsum;
+    red_sum(k & 1, jsum, vsum);
     // global active compensation (main.py:45-57)
     const float p_global = (gsum.x + vsum) + jsum;
     float lam;
@@ -400,7 +432,7 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
     if (low1) lam = (p_global - gsum.z) / (2.f * (gsum.y - gsum.z));
     else lam = (p_global - 2.f * gsum.y + gsum.w) / (2.f * (gsum.w - gsum.y));
     const bool low2 = lam < 0.5f;
-    if (A.save && wave == 0)
+    if (A.save && cw == 0)
       reinterpret_cast<f2*>(A.lam)[((long long)k * A.G + g) * GNS_LANES + lane] = f2{lam, (low1 ? 1.f : 0.f) + (low2 ? 2.f : 0.f)};
     float sq = 0.f;
     for (int nb = q0w; nb < q1w; nb += 4) {                           // four buses per round: their 8 row loads fly together
@@ -424,7 +456,7 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
     }
     tot_part += A.gw[k] * (sq * invN);           // main.py:198
     last_part = sq * invN;                                            // main.py:199
-    __syncthreads();                                                  // dp_{k+1} is complete before any wave starts step k+1
+    team_barrier(team);                                               // dp_{k+1} is complete before any wave starts step k+1
     FSTAMP(4)
   }
 #ifdef GNS_STAMPS
@@ -440,13 +472,13 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
       A.theta_out[b * N + n] = sn.y;
     }
   }
-  __syncthreads();
-  red[0][wave][lane][0] = tot_part;
-  red[0][wave][lane][1] = last_part;
-  __syncthreads();
-  if (wave == 0 && live) {
-    float t = 0.f, l = 0.f;
-    for (int w = 0; w < nwaves; ++w) { t += red[0][w][lane][0]; l += red[0][w][lane][1]; }
+  team_barrier(team);
+  red_put(0, tot_part, last_part);
+  team_barrier(team);
+  if (cw == 0 && live) {
+    float t, l;
+    red_sum(0, t, l);
+    if (team_failed) t = l = __builtin_nanf("");                     // a team barrier gave up: fail loudly
     A.total_out[b] = t;
     A.last_out[b] = l;
   }
@@ -466,7 +498,7 @@ static int launch_forward_t(const GnsFwdArgs& A, int threads, hipStream_t st) {
     }
     attr_ok[dev] = true;
   }
-  hipLaunchKernelGGL((gns_forward_kernel<D, H, MULTI>), dim3((unsigned)A.G), dim3(threads), dyn, st, A);
+  hipLaunchKernelGGL((gns_forward_kernel<D, H, MULTI>), dim3((unsigned)(A.G * A.team)), dim3(threads), dyn, st, A);
   return hipGetLastError() == hipSuccess ? GNS_OK : GNS_ELAUNCH;
 }
 

@@ -42,6 +42,8 @@ struct GnsFwdArgs {
   long long Bt, G;
   int N, E, K, save, part_idx;
   int plane;              // 1: the (v, theta) of the step being produced is mirrored in LDS ([N][64] float2, dynamic shared memory)
+  int team;               // workgroups per 64-grid group (1 = none); part_idx then names the partition for team * waves
+  unsigned char* team_ws; // team > 1: [G] 64-byte counter lines (zero at launch) | [G][GNS_TEAM_RED_FLOATS] partial sums
 };
 
 struct GnsBwdArgs {
@@ -59,6 +61,7 @@ struct GnsBwdArgs {
   float gw[GNS_MAX_K];
   long long Bt, G, slab_floats;
   int N, E, K, part_idx;
+  int team; unsigned char* team_ws;      // as in GnsFwdArgs; blocks = teams * team, slabs per (block, wave)
   int slab_dirty;                        // 1: the slabs were NOT zeroed by the caller; the V2 sweep stores (instead of adding) on a workgroup's first group
 };
 

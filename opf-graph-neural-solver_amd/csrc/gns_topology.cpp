@@ -16,7 +16,7 @@ struct Blob {
   void put(int slot, const std::vector<int32_t>& a) { w[slot] = (int32_t)w.size(); w.insert(w.end(), a.begin(), a.end()); }
 };
 
-// contiguous ranges over `cost`, balanced for `waves` parts, written to out[0..GNS_MAXW]
+// contiguous ranges over `cost`, balanced for `waves` parts, written to out[0..GNS_MAXP]
 void balanced_ranges(const std::vector<double>& cost, int waves, int32_t* out) {
   const int n = (int)cost.size();
   double total = std::accumulate(cost.begin(), cost.end(), 0.0);
@@ -27,9 +27,9 @@ void balanced_ranges(const std::vector<double>& cost, int waves, int32_t* out) {
     // cut after element i once this part holds its share; leave at least one element for each remaining part when possible
     while (w < waves && run >= total * w / waves - 1e-9) { out[w] = std::min(i + 1, n); ++w; }
   }
-  for (; w <= GNS_MAXW; ++w) out[w] = n;
-  for (w = 1; w <= GNS_MAXW; ++w) out[w] = std::max(out[w], out[w - 1]);
-  for (w = waves; w <= GNS_MAXW; ++w) out[w] = n;
+  for (; w <= GNS_MAXP; ++w) out[w] = n;
+  for (w = 1; w <= GNS_MAXP; ++w) out[w] = std::max(out[w], out[w - 1]);
+  for (w = waves; w <= GNS_MAXP; ++w) out[w] = n;
 }
 
 int build(int N, int E, int Gn, const int32_t* src, const int32_t* dst, const int32_t* gen_bus, std::vector<int32_t>& out) {
@@ -92,8 +92,8 @@ int build(int N, int E, int Gn, const int32_t* src, const int32_t* dst, const in
     // measured on MI355X (case118): these weights balance the 8 waves within +-10 %; lighter line weights were slower
     cost[n] = 950.0 + 1075.0 * din + 150.0 * dout + 10.0 * (incd_ptr[n + 1] - incd_ptr[n]);
   }
-  std::vector<int32_t> part(GNS_NPART * (GNS_MAXW + 1)), epart(GNS_NPART * (GNS_MAXW + 1));
-  std::vector<int32_t> upart(GNS_NPART * (GNS_MAXW + 1)), ppart(GNS_NPART * (GNS_MAXW + 1));
+  std::vector<int32_t> part(GNS_NPART * (GNS_MAXP + 1)), epart(GNS_NPART * (GNS_MAXP + 1));
+  std::vector<int32_t> upart(GNS_NPART * (GNS_MAXP + 1)), ppart(GNS_NPART * (GNS_MAXP + 1));
   // forward: (family, bus) units in family-major order (one family's weights stay hot in the scalar cache);
   // packed-FMA instruction estimates of the folded networks: L' ~ 300 (theta, v) / 400 (m), phi' ~ 190 per line
   // forward update phase: units u = grp * N + n with grp 0 = (theta, v) families together, grp 1 = m family;
@@ -107,12 +107,12 @@ int build(int N, int E, int Gn, const int32_t* src, const int32_t* dst, const in
   // (waves of a workgroup do not run at equal speed: VALU issue favours the older waves of a SIMD, so the youngest four
   //  finish last whatever they are given; weighting their share down was measured slower, the SIMD total is what counts)
   for (int n = 0; n < N; ++n) pcost[n] = 60.0 + 130.0 * (in_ptr[n + 1] - in_ptr[n]) + 80.0 * (out_ptr[n + 1] - out_ptr[n]);
-  const int wopts[GNS_NPART] = {1, 2, 4, 8, 16};
+  const int wopts[GNS_NPART] = {1, 2, 4, 8, 16, 32};
   for (int i = 0; i < GNS_NPART; ++i) {
-    balanced_ranges(cost, wopts[i], &part[i * (GNS_MAXW + 1)]);
-    balanced_ranges(ecost, wopts[i], &epart[i * (GNS_MAXW + 1)]);
-    balanced_ranges(ucost, wopts[i], &upart[i * (GNS_MAXW + 1)]);
-    balanced_ranges(pcost, wopts[i], &ppart[i * (GNS_MAXW + 1)]);
+    balanced_ranges(cost, wopts[i], &part[i * (GNS_MAXP + 1)]);
+    balanced_ranges(ecost, wopts[i], &epart[i * (GNS_MAXP + 1)]);
+    balanced_ranges(ucost, wopts[i], &upart[i * (GNS_MAXP + 1)]);
+    balanced_ranges(pcost, wopts[i], &ppart[i * (GNS_MAXP + 1)]);
   }
 
   b.put(TH_IN_PTR, in_ptr); b.put(TH_IN_EID, in_eid); b.put(TH_IN_SRC, in_src); b.put(TH_IN_A, in_a); b.put(TH_IN_B, in_b);
@@ -138,7 +138,7 @@ int build(int N, int E, int Gn, const int32_t* src, const int32_t* dst, const in
 
 size_t blob_words(int N, int E, int Gn) {
   return TH_HDR_WORDS + 2 * (size_t)(N + 1) + 12 * (size_t)E + (size_t)N + (size_t)(N + 1) + (size_t)std::max(Gn, 1)
-         + 4 * (size_t)GNS_NPART * (GNS_MAXW + 1) + (size_t)(N + 1) + 5 * (size_t)E + (size_t)N;
+         + 4 * (size_t)GNS_NPART * (GNS_MAXP + 1) + (size_t)(N + 1) + 5 * (size_t)E + (size_t)N;
 }
 
 }  // namespace

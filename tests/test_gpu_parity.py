@@ -94,6 +94,60 @@ def test_parameter_gradient_matches_reference_autograd(name, dw_engine):
             assert float(p.grad.abs().max()) == 0.0, n
 
 
+@pytest.fixture
+def lane_mapping():
+    """Pin both the evaluation and the training calls to the lane-per-grid kernels (small batches default to the other pair)."""
+    import opf_graph_neural_solver_amd as amd
+    old = amd.get_option('fwd_mapping'), amd.get_option('train_mapping'), amd.get_option('team')
+    amd.set_option('fwd_mapping', 1); amd.set_option('train_mapping', 1)
+    yield amd
+    amd.set_option('fwd_mapping', old[0]); amd.set_option('train_mapping', old[1]); amd.set_option('team', old[2])
+
+
+@pytest.mark.parametrize('team', [1, 2, 4])
+@pytest.mark.parametrize('name', ['c14_b3_K4_d20_multi_lowload', 'c118_b2_K4_d20_multi', 'c118_b2_K4_d20_single', 'c300_b1_K10_d20_multi'])
+def test_teams_of_workgroups_match_reference_goldens(name, team, lane_mapping):
+    """A batch with fewer 64-grid groups than CUs is worked by teams of 2 or 4 workgroups per group (gns_device.h, "teams":
+    barrier through an HBM counter, partial sums through HBM).  Forward outputs and parameter gradients against the
+    reference's, for every team size; team 1 is the single-workgroup kernel."""
+    lane_mapping.set_option('team', team)
+    g = load_golden(name)
+    m = _model(g)
+    bu, li, ge = t(g['buses']).cuda(), t(g['lines']).cuda(), t(g['generators']).cuda()
+    with torch.no_grad():
+        v, th, tot, last = m(bu, li, ge)
+    assert_close(v.cpu(), g['v'], REL, what='v')
+    assert_close(th.cpu(), g['theta'], REL, what='theta')
+    assert_close(tot.cpu(), g['total_loss'], REL, what='total_loss')
+    v, th, tot, last = m(bu, li, ge)
+    assert_close(last.detach().cpu(), g['last_loss'], REL, what='last_loss (training mode)')
+    tot.mean().backward()
+    grad = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).cpu().numpy()
+    assert_close(grad, g['grad_params'], 5e-5, abs_floor=1e-7, what='grad_params')
+
+
+@pytest.mark.parametrize('case,bt,d,multi,K', [(118, 4099, 20, True, 4), (300, 130, 20, True, 10), (30, 8000, 10, False, 3), (118, 8192, 10, True, 6)])
+def test_teams_agree_with_single_workgroups_on_partial_chip_batches(case, bt, d, multi, K, lane_mapping):
+    """Many teams at once (65 groups x 2, 3 x 4, 125 x 2, 128 x 2 workgroups), ragged last group: the team kernels give the
+    single-workgroup kernels' outputs and gradients up to the order of the per-wave partial sums."""
+    amd = lane_mapping
+    torch.manual_seed(4)
+    m = amd.GNS(d, 10, K, 0.9, multi).cuda()
+    bu, li, ge = amd.synth.synth_grids(case, bt, seed=21, device='cuda')
+    res = {}
+    for team in (1, 0):
+        amd.set_option('team', team)
+        m.zero_grad()
+        with torch.no_grad():
+            ev = m(bu, li, ge)
+        out = m(bu, li, ge)
+        out[2].mean().backward()
+        res[team] = [x.detach().clone() for x in ev] + [x.detach().clone() for x in out] + [torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()]
+    for a, b, what in zip(res[1], res[0], ['v', 'theta', 'total', 'last', 'v (train)', 'theta (train)', 'total (train)', 'last (train)', 'grad']):
+        assert torch.isfinite(b).all(), what
+        assert_close(b.cpu(), a.cpu(), 2e-5 if what == 'grad' else 2e-6, abs_floor=1e-7, what=what)
+
+
 @pytest.mark.parametrize('case,bt,d,multi,K,pack', [(118, 4099, 20, True, 4, 1), (118, 1030, 20, True, 4, 4), (30, 777, 10, False, 3, 3),
                                                     (14, 2001, 10, True, 2, 16), (300, 130, 20, True, 10, 1), (118, 257, 10, True, 15, 2)])
 def test_forward_mappings_agree_on_large_batches(case, bt, d, multi, K, pack):
@@ -248,8 +302,17 @@ def test_full_size_batch_against_oracle_sample_and_properties(train_mapping):
         assert torch.equal(vs, ve[100:229]) and torch.equal(ths, the[100:229]) and torch.equal(tots, tote[100:229])
         assert_close(ve.cpu(), v.detach().cpu(), 2e-6, what='eval vs train v')
         assert_close(the.cpu(), th.detach().cpu(), 2e-6, what='eval vs train theta')
-        vt, tht, tott, _ = m(bu[100:229], li[100:229], ge[100:229])          # training-mode slice
+        # training-mode slice: bitwise with the same number of workgroups per 64-grid group; a small batch alone is worked by
+        # teams of workgroups (other split of the buses -> other order of the per-wave partial sums of lambda and the loss)
+        old_team = amd.get_option('team')
+        groups = (bt + 63) // 64
+        amd.set_option('team', 4 if groups * 4 <= 256 else (2 if groups * 2 <= 256 else 1))    # what the whole batch ran with
+        vt, tht, tott, _ = m(bu[100:229], li[100:229], ge[100:229])
+        amd.set_option('team', old_team)
         assert torch.equal(vt, v[100:229]) and torch.equal(tht, th[100:229]) and torch.equal(tott, tot[100:229])
+        vt, tht, tott, _ = m(bu[100:229], li[100:229], ge[100:229])
+        assert_close(vt.detach().cpu(), v[100:229].detach().cpu(), 2e-6, what='slice in teams v')
+        assert_close(tott.detach().cpu(), tot[100:229].detach().cpu(), 2e-6, what='slice in teams total')
         # (d) mean of two half-batch gradients == full-batch gradient
         halves = []
         for lo, hi in ((0, bt // 2), (bt // 2, bt)):

@@ -103,14 +103,14 @@ def test_topology_blob(case):
         assert arr('OUT_DST', E)[q] == tt and arr('OUT_C', E)[q] == src[tt] and arr('OUT_D', E)[q] == dst[tt]
         assert in_order[arr('Q2P', E)[q]] == e
     assert set(np.nonzero(arr('IS_GEN', N))[0]) == set(gen.tolist())
-    for wi, W in enumerate((1, 2, 4, 8, 16)):
-        part = blob[blob[H['PART']] + wi * 17: blob[H['PART']] + wi * 17 + 17]
+    for wi, W in enumerate((1, 2, 4, 8, 16, 32)):
+        part = blob[blob[H['PART']] + wi * 33: blob[H['PART']] + wi * 33 + 33]
         assert part[0] == 0 and part[W] == N and np.all(np.diff(part) >= 0)
     incd_ptr = arr('INCD_PTR', N + 1)
     assert incd_ptr[N] == 4 * E
-    for wi, W in enumerate((1, 2, 4, 8, 16)):
-        up = blob[blob[H['UPART']] + wi * 17: blob[H['UPART']] + wi * 17 + 17]
-        pp = blob[blob[H['PPART']] + wi * 17: blob[H['PPART']] + wi * 17 + 17]
+    for wi, W in enumerate((1, 2, 4, 8, 16, 32)):
+        up = blob[blob[H['UPART']] + wi * 33: blob[H['UPART']] + wi * 33 + 33]
+        pp = blob[blob[H['PPART']] + wi * 33: blob[H['PPART']] + wi * 33 + 33]
         assert up[0] == 0 and up[W] == 2 * N and np.all(np.diff(up) >= 0)        # (family group, bus) units of the forward update phase
         assert pp[0] == 0 and pp[W] == N and np.all(np.diff(pp) >= 0)
 
