@@ -127,6 +127,9 @@ int gns_profile_read(int backward, float* ms_sum, int* launches);
  *   "bwd_variant" family sweep of the lane-per-grid backward: 1 wide half-wave records | 2 layer-wise sweep with sub-record
  *                 windows (default) | 3 = 2 with the contraction chains issued behind the weight streams
  *   "dw_mfma"     0: weight-gradient contraction on packed FMAs instead of the fp32 matrix pipe
+ *   "team"        lane-per-grid kernels, batches with fewer 64-grid groups than CUs: workgroups per group, 0 auto (as many
+ *                 as keep every workgroup resident) | 1 none | 2 | 4.  Teams meet at counters in the workspace; two team
+ *                 kernels in flight at once on one device may starve each other (bounded: NaN results, never a hang)
  * Both mappings and both engines compute the same function of the reference (GNS/main.py:140-202, :288). */
 int gns_set_option(const char* name, int value);
 int gns_get_option(const char* name, int* value);

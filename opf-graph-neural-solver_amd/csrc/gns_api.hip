@@ -342,7 +342,7 @@ extern "C" int gns_forward(const gns_config* cfg, const void* topo_dev, const fl
   int waves = T.fwd_waves;
   while (waves * A.team > GNS_MAXP) waves /= 2;
   A.part_idx = gns_part_index(waves * A.team);
-  A.plane = ((size_t)N * GNS_LANES * 2 * sizeof(float) <= (size_t)GNS_PLANE_MAX_BYTES && T.fwd_plane) ? 1 : 0;
+  A.plane = (gns_fwd_plane_fits(N, A.team) && T.fwd_plane) ? 1 : 0;
   if (A.team > 1 && hipMemsetAsync(A.team_ws, 0, (size_t)L.groups * GNS_TEAM_CTR_BYTES, st) != hipSuccess) return GNS_ELAUNCH;
   prof_mark(0, true, st);
   rc = gns_launch_forward(d, h, cfg->multiple_phi, A, waves * 64, st);

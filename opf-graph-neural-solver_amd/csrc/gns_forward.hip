@@ -200,9 +200,13 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
   const long long b = g * GNS_LANES + lane;
   const bool live = b < A.Bt;
 
-  __shared__ float red[2][GNS_MAXW][GNS_LANES][2];
   // (v, theta) of every bus of the 64 grids for the step being produced, written by the update phase and gathered by
   // the line physics (6 neighbour buses per line): 60 KB for case118 instead of ~19 HBM rows per bus and step.
+  extern __shared__ __attribute__((aligned(16))) unsigned char gns_dyn_lds[];
+  f2* plane = reinterpret_cast<f2*>(gns_dyn_lds);
+  const bool use_plane = A.plane != 0;
+  // per-wave partial sums [2 parities][GNS_MAXW][64][2] behind the plane; a team keeps them in HBM and the LDS goes to the plane
+  float* red = reinterpret_cast<float*>(gns_dyn_lds + (use_plane ? (size_t)N * GNS_LANES * sizeof(f2) : 0));
   __shared__ int unit_ctr[2];                        // evaluation mode: work queue of the update phase, one counter per step parity
   __shared__ int team_failed;
   if (threadIdx.x < 2) unit_ctr[threadIdx.x] = 0;
@@ -215,17 +219,14 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
   team_setup(team, team.ctr);
   // per-wave partial sums: LDS inside one workgroup, the group's HBM buffer across a team
   auto red_put = [&](int par, float a, float c) {
-    if (tsize == 1) { red[par][wave][lane][0] = a; red[par][wave][lane][1] = c; }
+    if (tsize == 1) *reinterpret_cast<f2*>(red + ((par * GNS_MAXW + wave) * GNS_LANES + lane) * 2) = f2{a, c};
     else reinterpret_cast<f2*>(team.red)[(par * GNS_MAXP + cw) * GNS_LANES + lane] = f2{a, c};
   };
   auto red_sum = [&](int par, float& a, float& c) {
     a = 0.f; c = 0.f;
-    if (tsize == 1) { for (int w = 0; w < nwaves; ++w) { a += red[par][w][lane][0]; c += red[par][w][lane][1]; } }
+    if (tsize == 1) { for (int w = 0; w < nwaves; ++w) { const f2 r = *reinterpret_cast<const f2*>(red + ((par * GNS_MAXW + w) * GNS_LANES + lane) * 2); a += r.x; c += r.y; } }
     else for (int w = 0; w < tw; ++w) { const f2 r = reinterpret_cast<const f2*>(team.red)[(par * GNS_MAXP + w) * GNS_LANES + lane]; a += r.x; c += r.y; }
   };
-  extern __shared__ __attribute__((aligned(16))) unsigned char gns_dyn_lds[];
-  f2* plane = reinterpret_cast<f2*>(gns_dyn_lds);
-  const bool use_plane = A.plane != 0;
 
   auto state_row = [&](int slot, int n) { return (((long long)slot * A.G + g) * N + n) * RB; };
 
@@ -486,13 +487,12 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
 
 template <int D, int H, bool MULTI>
 static int launch_forward_t(const GnsFwdArgs& A, int threads, hipStream_t st) {
-  const size_t dyn = A.plane ? (size_t)A.N * GNS_LANES * sizeof(f2) : 0;
-  static_assert(sizeof(float) * 2 * GNS_MAXW * GNS_LANES * 2 + 2 * sizeof(int) <= GNS_FWD_STATIC_LDS_BYTES, "static LDS of the forward kernel");
+  const size_t dyn = (A.plane ? (size_t)A.N * GNS_LANES * sizeof(f2) : 0) + (A.team == 1 ? (size_t)GNS_FWD_RED_BYTES : 0);
   static bool attr_ok[64] = {};                                      // > 64 KB of dynamic LDS needs the opt-in, once per kernel and device
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   if (dyn > 64 * 1024 && !attr_ok[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gns_forward_kernel<D, H, MULTI>), hipFuncAttributeMaxDynamicSharedMemorySize, GNS_PLANE_MAX_BYTES) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gns_forward_kernel<D, H, MULTI>), hipFuncAttributeMaxDynamicSharedMemorySize, GNS_FWD_DYN_LDS_MAX) != hipSuccess) {
       (void)hipGetLastError();
       return GNS_ELAUNCH;
     }

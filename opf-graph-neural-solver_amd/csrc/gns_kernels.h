@@ -8,10 +8,14 @@
 #define GNS_FWD_MAX_THREADS 1024 // register budget of the forward kernel: 128 VGPRs -> 4 waves/SIMD
 #define GNS_BWD_THREADS 512
 #define GNS_MAX_K 64
-// forward (lane-per-grid): LDS budget of the dynamic (v, theta) plane = the CU's 160 KiB minus the kernel's static LDS
-// (red[2][GNS_MAXW][64][2] floats + the unit counters); larger cases read neighbours from HBM
-#define GNS_FWD_STATIC_LDS_BYTES (2 * GNS_MAXW * GNS_LANES * 2 * 4 + 64)
-#define GNS_PLANE_MAX_BYTES (160 * 1024 - GNS_FWD_STATIC_LDS_BYTES)
+// forward (lane-per-grid): dynamic LDS = the (v, theta) plane [N][64] float2 (when it fits) + the per-wave partial sums
+// red[2][GNS_MAXW][64][2] (a team keeps those in HBM, which is what lets the case300 plane fit); larger cases read
+// neighbours from HBM.  Static LDS: the unit counters and the team flag.
+#define GNS_FWD_RED_BYTES (2 * GNS_MAXW * GNS_LANES * 2 * 4)
+#define GNS_FWD_DYN_LDS_MAX (160 * 1024 - 64)
+static inline int gns_fwd_plane_fits(int N, int team) {
+  return (size_t)N * GNS_LANES * 8 + (team == 1 ? GNS_FWD_RED_BYTES : 0) <= (size_t)GNS_FWD_DYN_LDS_MAX;
+}
 
 // (latent_dim, hidden_dim) pairs with compiled kernels
 #define GNS_FOR_EACH_DIMS(X) X(20, 10) X(10, 10)

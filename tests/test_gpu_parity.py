@@ -807,6 +807,53 @@ def test_config5_shape_case300_K10_batched():
     assert_close(grad, fo.grad, 5e-5, abs_floor=1e-6, what='grad case300 K=10')
 
 
+def test_config5_per_gpu_batch_case300_x_8192_K10():
+    """BASELINE config 5 at its per-GPU size (65 536 / 8 = 8 192 case300 grids, K=10, three phis): 128 wave-groups worked by
+    teams of two workgroups.  Forward outputs and the gradient of a weighted loss against the CPU oracle on a sample of grids
+    from both ends and the middle of the batch; run-to-run bitwise reproducibility; the batch gradient as the mean of the two
+    half-batch gradients (which run as 64 groups x 4 workgroups)."""
+    import opf_graph_neural_solver_amd as amd
+    from oracle import gns_oracle as orc
+    torch.manual_seed(6)
+    m = amd.GNS(20, 10, 10, 0.9, True).cuda()
+    bt = 8192
+    bu, li, ge = amd.synth.synth_grids(300, bt, seed=15, device='cuda')
+    v, th, tot, last = m(bu, li, ge)
+    assert all(torch.isfinite(x).all() for x in (v, th, tot, last))
+    sample = [0, 4097, bt - 1]
+    w = torch.zeros(bt, device='cuda')
+    w[sample] = 1.0
+    (tot * w).sum().backward()
+    grad = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).cpu()
+    fo = m.flat_parameters().detach().cpu().clone().requires_grad_(True)
+    po = orc.unflatten_params(fo, 20, 10, 10, True)
+    acc = 0.
+    for b in sample:
+        vo, tho, toto, lasto = orc.gns_forward(po, bu[b].cpu(), li[b].cpu(), ge[b].cpu(), latent_dim=20, K=10, gamma=0.9, multiple_phi=True)
+        assert_close(v[b].detach().cpu(), vo.detach(), REL, what=f'v[{b}]')
+        assert_close(th[b].detach().cpu(), tho.detach(), REL, what=f'theta[{b}]')
+        assert_close(tot[b].detach().cpu(), toto.detach(), REL, what=f'total[{b}]')
+        acc = acc + toto
+    acc.backward()
+    assert_close(grad, fo.grad, 5e-5, abs_floor=1e-6, what='grad case300 K=10, 8192 grids')
+    m.zero_grad()
+    v1, th1, tot1, _ = m(bu, li, ge)
+    tot1.mean().backward()
+    g_all = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
+    m.zero_grad()
+    v2, th2, tot2, _ = m(bu, li, ge)
+    tot2.mean().backward()
+    g_again = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
+    assert torch.equal(v1, v2) and torch.equal(th1, th2) and torch.equal(tot1, tot2) and torch.equal(g_all, g_again)
+    halves = []
+    for lo, hi in ((0, bt // 2), (bt // 2, bt)):
+        m.zero_grad()
+        _, _, t_h, _ = m(bu[lo:hi], li[lo:hi], ge[lo:hi])
+        t_h.mean().backward()
+        halves.append(torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone())
+    assert_close((0.5 * (halves[0] + halves[1])).cpu(), g_all.cpu(), 2e-5, abs_floor=1e-7, what='half-batch mean')
+
+
 def test_c_abi_calls_are_graph_capturable():
     """include/gns_hip.h promises no allocation / synchronisation / host copies inside gns_forward: capture an inference
     call into a HIP graph (torch.cuda.graph), replay it on new inputs and compare with the eager result."""
