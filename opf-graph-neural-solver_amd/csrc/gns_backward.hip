@@ -74,8 +74,14 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
   long long tph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast = clock64();
 #define STAMP(i) { const long long tn = clock64(); tph[i] += tn - tlast; tlast = tn; }
+  // finer segments inside the V2 family sweep; every stamp first drains the wave's outstanding memory operations, so a
+  // segment is charged with its own latencies (this serialises what normally overlaps: shares, not absolute times)
+  long long tsw[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tl2 = clock64();
+#define SSTAMP(i) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long tn = clock64(); tsw[i] += tn - tl2; tl2 = tn; }
 #else
 #define STAMP(i)
+#define SSTAMP(i)
 #endif
   if constexpr (V2) {
     if (A.slab_dirty) {     // the two blocks no sweep touches (L_m.{K-1}, phi_m.{K-1}: no gradient in the reference) must still read as zero
@@ -529,6 +535,7 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
 #pragma unroll
         for (int t = 0; t < NDM; ++t) TPm[t] = z4;
         T2 = z4; TP1 = z4; TP2 = z4;
+        SSTAMP(11)
         for (int n = n0; n < n1; ++n) {
           const long long ar = adj_row(n), rr = state_row(k, n);
           const f4 a0 = *row_ptr(A.adj, ar, lane);
@@ -549,9 +556,11 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
           xs[0] = f2{s0.x, s0.y}; xs[1] = f2{s0.z, s0.w};
           xs[XL - 1] = f2{(float)(p1 - p0), 1.f};             // deg, and the 1 whose column of dW1 is db1
           f2 gS[H / 2];                                       // adjoint of the hidden-vector sum: what every line ending at n receives
+          SSTAMP(0)
           {
             f2 a1[H / 2], a2[H / 2], g2[H / 2], g1[H / 2];
             mlp2_fwd<LIN, H>(PT + A.t_off[C::NPHI + l] + koff * A.t_sz[C::NPHI + l], xs, a1, a2);
+            SSTAMP(1)
             // output layer: g2 = (W4^T g3) * lrelu'(a2);  dW4 | db4 += g3 (x) [a2 | 1]
             if constexpr (l == 2) {
               bwd_rows<OUTP, H>(nb, macc, g2);                                          // m += L_m (main.py:188)
@@ -572,6 +581,7 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
               }
               gws_w2r(); gws_pass(rec, lane, T4[t]); gws_r2w();
             });
+            SSTAMP(2)
             // hidden layer: g1 = (W2^T g2) * lrelu'(a1);  dW2 | db2 += g2 (x) [a1 | 1]
             bwd_rows<H, H>(nb + NL::oW2, g2, g1);
 #pragma unroll
@@ -579,6 +589,7 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
             static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA(rec, lane, j, g2[j]); gws_putB(rec, lane, j, a1[j]); });
             gws_putB(rec, lane, H / 2, f2{1.f, 0.f});
             gws_w2r(); gws_pass(rec, lane, T2); gws_r2w();
+            SSTAMP(3)
             // first layer: dW1 | db1 += g1 (x) [x | 1] in 16-column windows
             static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA(rec, lane, j, g1[j]); });
             static_for<0, NB1>([&](auto t_) {
@@ -586,6 +597,7 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
               static_for<0, 8>([&](auto j_) { constexpr int j = decltype(j_)::value; if constexpr (8 * t + j < XL) gws_putB(rec, lane, j, xs[8 * t + j]); });
               gws_w2r(); gws_pass(rec, lane, T1[t]); gws_r2w();
             });
+            SSTAMP(4)
             // input adjoints, four at a time, straight to their consumers
             bwd_inputs<(LIN + 3) / 4, H>(nb + NL::total, g1, [&](auto ip_, f2 v) {
               constexpr int ip = decltype(ip_)::value;
@@ -595,9 +607,11 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
               else if constexpr (ip < SOFF + H / 2) gS[ip - SOFF] = v;
             });
           }
+          SSTAMP(5)
           if (p0 < p1) {                                      // back through the hidden vectors of the lines ending at n
             f2 uh[H / 2], G1[H / 2];
             phi_head<D, H>(ptb, m, uh);
+            SSTAMP(6)
 #pragma unroll
             for (int j = 0; j < H / 2; ++j) G1[j] = f2{0.f, 0.f};
             for (int p = p0; p < p1; ++p) {
@@ -614,12 +628,14 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
               bwd_rows<H, H>(pnb, g2, g1);
 #pragma unroll
               for (int u = 0; u < H / 2; ++u) { g1[u] = g1[u] * dlrelu2(a1[u]); G1[u] += g1[u]; }
+              SSTAMP(7)
               static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA(rec, lane, j, g1[j]); });
               gws_putB(rec, lane, 0, xt[0]); gws_putB(rec, lane, 1, xt[1]); gws_putB(rec, lane, 2, f2{xt[2].x, 1.f});
               gws_w2r(); gws_pass(rec, lane, TP1); gws_r2w();
               static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA(rec, lane, j, g2[j]); gws_putB(rec, lane, j, a1[j]); });
               gws_putB(rec, lane, H / 2, f2{1.f, 0.f});
               gws_w2r(); gws_pass(rec, lane, TP2); gws_r2w();
+              SSTAMP(8)
             }
             // x = [m(dst) | ...] (main.py:155): d/dm += W1[:, :d]^T G1 and the latent columns of dW1 += G1 (x) m, once per bus
             bwd_inputs<(D + 3) / 4, H>(pnb + NLay2<PIN, H>::total, G1, [&](auto ip_, f2 v) {
@@ -633,8 +649,10 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
               gws_w2r(); gws_pass(rec, lane, TPm[t]); gws_r2w();
             });
           }
+          SSTAMP(9)
           *row_ptr(A.adj, ar + 1, lane) = xsum;
           store_pairs<D>(A.adj, ar + RM, lane, macc);
+          SSTAMP(10)
         }
         {   // flush the family's tiles into the wave's slab (folded blocks: W1[H][IN] b1 W2 b2 [W4 b4])
           constexpr int ob1 = LIN * H, oW2 = ob1 + H, ob2 = oW2 + H * H, oW4 = ob2 + H, ob4 = oW4 + OUT * H;
@@ -761,6 +779,7 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
   if (team_failed && lane == 0) slab[0] = __builtin_nanf("");          // a team barrier gave up: the gradients must not look valid
 #ifdef GNS_STAMPS
   if (lane == 0) for (int i = 0; i < 10; ++i) A.slots[((long long)blockIdx.x * W + wave) * 10 + i] = (float)tph[i];   // diagnostic build only: slots are dead by now
+  if (lane == 0) for (int i = 0; i < 12; ++i) A.slots[(long long)gridDim.x * W * 10 + ((long long)blockIdx.x * W + wave) * 12 + i] = (float)tsw[i];
 #endif
 }
 

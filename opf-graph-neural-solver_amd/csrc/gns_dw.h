@@ -554,6 +554,7 @@ __device__ __forceinline__ void gws_pass(const float* rec, int lane, f32x4& Dt) 
   return;
 #endif
   const float* base = rec + (((lane >> 5) & 1) + 4 * ((lane >> 4) & 1)) * GwSub::RS + (lane & 15);
+#ifdef GNS_PASS_HALVES          // the round-2 schedule: operands of 8 k-steps, their 8 MFMAs, twice
   static_for<0, 2>([&](auto h_) {
     constexpr int hh = decltype(h_)::value;
     float Aop[8], Bop[8];
@@ -569,6 +570,29 @@ __device__ __forceinline__ void gws_pass(const float* rec, int lane, f32x4& Dt) 
     });
     __builtin_amdgcn_sched_barrier(0);
   });
+#else
+  // Operand ring of GWS_AHEAD k-steps: the LDS read of step kk + AHEAD is issued right behind the MFMA of step kk, so the
+  // matrix pipe never waits for a batch of reads (8 operand registers instead of 16).
+#ifndef GWS_AHEAD
+#define GWS_AHEAD 4
+#endif
+  constexpr int AH = GWS_AHEAD;
+  float Aop[AH], Bop[AH];
+  auto rd = [&](auto kk_) {
+    constexpr int kk = decltype(kk_)::value;
+    const float* b = base + (8 * (kk >> 1) + 2 * (kk & 1)) * GwSub::RS;
+    Aop[kk % AH] = b[0];
+    Bop[kk % AH] = b[GwSub::NA];
+  };
+  static_for<0, AH>([&](auto kk_) { rd(kk_); });
+  __builtin_amdgcn_sched_barrier(0);
+  static_for<0, 16>([&](auto kk_) {
+    constexpr int kk = decltype(kk_)::value;
+    Dt = __builtin_amdgcn_mfma_f32_16x16x4f32(Aop[kk % AH], Bop[kk % AH], Dt, 0, 0, 0);
+    if constexpr (kk + AH < 16) rd(std::integral_constant<int, kk + AH>{});
+    __builtin_amdgcn_sched_barrier(0);
+  });
+#endif
 }
 // slab_blk[idx_of(c, i)] += D[c][i] for the entries that map to a parameter (idx_of returns -1 otherwise)
 template <class F>

@@ -20,11 +20,12 @@ ws = torch.empty(fw.value, dtype=torch.uint8, device='cuda'); bws = torch.zeros(
 v = torch.empty(bt, N, device='cuda'); th = torch.empty_like(v); tot = torch.empty(bt, device='cuda'); last = torch.empty_like(tot)
 gt = torch.full((bt,), 1.0 / bt, device='cuda'); grad = torch.zeros_like(flat)
 st = torch.cuda.current_stream().cuda_stream
+amd.set_option('train_mapping', 1)
 for it in range(2):
-    assert lib.gns_forward(ctypes.byref(cfg), topo.blob.data_ptr(), flat.data_ptr(), bu.data_ptr(), li.data_ptr(), ge.data_ptr(), bt,
+    assert lib.gns_forward(ctypes.byref(cfg), topo.blob.data_ptr(), flat.data_ptr(), bu.data_ptr(), li.data_ptr(), ge.data_ptr(), bt, None,
                            v.data_ptr(), th.data_ptr(), tot.data_ptr(), last.data_ptr(), ws.data_ptr(), ws.numel(), 1, st) == 0
-    assert lib.gns_backward(ctypes.byref(cfg), topo.blob.data_ptr(), flat.data_ptr(), bt, ws.data_ptr(), ws.numel(), gt.data_ptr(), None, None, None,
-                            grad.data_ptr(), bws.data_ptr(), bws.numel(), st) == 0
+    assert lib.gns_backward(ctypes.byref(cfg), topo.blob.data_ptr(), flat.data_ptr(), bu.data_ptr(), li.data_ptr(), ge.data_ptr(), bt, None,
+                            ws.data_ptr(), ws.numel(), gt.data_ptr(), None, None, None, grad.data_ptr(), bws.data_ptr(), bws.numel(), st) == 0
 torch.cuda.synchronize()
 groups = (bt + 63) // 64
 RB = 1 + 5
@@ -41,3 +42,12 @@ print('per-wave totals of block 0 (wave 0..7):', ' '.join(f'{t:.0f}' for t in to
 print('wave-by-wave family-pass cycles, block 0:')
 for w in range(8):
     print('  wave', w, ' '.join(f'{names[i]}={st_[0, w, i]:.0f}' for i in (4, 5, 6, 7)))
+
+sub = bws[off_slots + blocks * 8 * 10 * 4: off_slots + blocks * 8 * 10 * 4 + blocks * 8 * 12 * 4].view(torch.float32).view(blocks, 8, 12).cpu().numpy()
+snames = ['row loads until complete', 'L\' recompute (mlp2_fwd)', 'output layer: W4^T rows + dW4 passes', 'hidden layer: W2^T rows + dW2 pass',
+          'dW1 windows (3 passes)', 'input adjoints (W1^T stream)', 'phi head', 'lines: tail + W2^T rows', 'lines: dW1/dW2 passes',
+          'G1 -> m adjoints + latent dW1 passes', 'row stores until complete', 'outside the bus loops (flush, physics phases)']
+print('V2 family sweeps, drained segments (shares of the stamped total; every stamp waits for the wave\'s memory operations):')
+for i, nme in enumerate(snames):
+    x = sub[:, :, i]
+    print(f'  {nme:46s} {100 * x.sum() / sub.sum():5.1f}%   per-wave mean {x.mean():10.0f} cycles')
