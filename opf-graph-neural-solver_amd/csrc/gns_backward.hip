@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
   const long long R = gns_in_rows(N, E);
   const float* IN = A.in;
 
-  constexpr int RECF = VAR == 3 ? 64 * 76 + 32 : V2 ? GwSub::RECF
+  constexpr int RECF = VAR == 3 ? 64 * 76 + 32 : V2 ? (D > 16 ? GwSubWide::RECF : GwSub::RECF)
                           : gns_cmax(GNS_REC_ROWS * gns_cmax(RecLay<C::LF_IN, H, D>::RS, RecLay<C::LF_IN, H, 1>::RS),
                                      2 * GNS_REC_ROWS * RecLay2<C::PHI_IN, H>::RS) + 32;   // +32: the MFMA variant reads 16-wide column blocks
   __shared__ __attribute__((aligned(16))) float rec_all[W][RECF];
@@ -522,6 +522,19 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
         constexpr int LIN = C::LF_IN, XL = (LIN + 1) / 2, PIN = C::PHI_IN, SOFF = 2 + D / 2;
         constexpr int NB1 = (2 * XL + 15) / 16, NA4 = (OUTP + 11) / 12, NDM = (D + 15) / 16;
         using NL = NLay<LIN, H, OUTP>;
+        // D > 16: 32-column window (GwSubWide).  Two products ride in passes that are issued anyway: the scalar output
+        // layer of L_theta / L_v (g3 (x) [a2 | 1], 11 entries) in row 10 of the last dW1 window, whose B columns 4..14 are
+        // spare, and the latent tail m[16..D) of phi's dW1 in the spare columns of every line's dW1 pass (the sum over the
+        // lines of g1 (x) m IS G1 (x) m: m belongs to the destination bus).  26.6 instead of 31.6 passes per bus and step.
+        constexpr bool WIDE = D > 16;
+        using SW = std::conditional_t<WIDE, GwSubWide, GwSub>;
+        constexpr bool FOLD4 = WIDE && l < 2 && (2 * XL - 16 * (NB1 - 1)) + H + 1 <= 16;   // [x tail | a2 | 1] fits one window
+        // L_m (d outputs > 16): one output-layer pass takes rows macc[0..15], the other d - 16 ride in rows 10.. of the same window
+        constexpr bool FOLDM = GwSubWide::NA >= 16 && WIDE && l == 2 && (2 * XL - 16 * (NB1 - 1)) + H + 1 <= 16 && H + (OUT - 16) <= 16;
+        constexpr int XT = 2 * XL - 16 * (NB1 - 1);                                          // x columns of the last dW1 window
+        constexpr int W2OFF = WIDE ? 16 - XT : 0;                                            // its first B column: the tail sits right below column 16
+        constexpr int NDMF = WIDE ? 1 : NDM;                                                 // latent tiles left after the fold
+        static_assert(!WIDE || ((D - 16) + (PIN - D) + 1 <= 16 && (PIN - D) % 2 == 1), "[line parameters | 1 | latent tail] in one window, the tail on a pair boundary");
         if (l == 2 && k == K - 1) return;
         cfp nb = PN + A.n_off[C::NPHI + l] + koff * A.n_sz[C::NPHI + l];
         cfp pnb = PN + A.n_off[fphi] + koff * A.n_sz[fphi];
@@ -535,6 +548,15 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
 #pragma unroll
         for (int t = 0; t < NDM; ++t) TPm[t] = z4;
         T2 = z4; TP1 = z4; TP2 = z4;
+        // Weight streams that follow each other closely are linked (gns_device.h, WLink): a stream fetches the first chunk of
+        // the next one in its own last step.  Only where nothing but a few vector instructions sits between them: held across a
+        // contraction pass the 32 scalar registers of a fetched chunk cost more in spills than the hidden latency is worth
+        // (all streams of a bus linked: 577 instead of 416 scalar spills, 2.70 instead of 2.62 ms).
+        cfp ptl = PT + A.t_off[C::NPHI + l] + koff * A.t_sz[C::NPHI + l];
+        WFirst wf;
+        using L0 = WLink<false, true>;            // first of a group
+        using L1 = WLink<true, true>;             // middle
+        using L2 = WLink<true, false>;            // last
         SSTAMP(11)
         for (int n = n0; n < n1; ++n) {
           const long long ar = adj_row(n), rr = state_row(k, n);
@@ -559,43 +581,55 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
           SSTAMP(0)
           {
             f2 a1[H / 2], a2[H / 2], g2[H / 2], g1[H / 2];
-            mlp2_fwd<LIN, H>(PT + A.t_off[C::NPHI + l] + koff * A.t_sz[C::NPHI + l], xs, a1, a2);
+            mlp2_fwd<LIN, H>(ptl, xs, a1, a2, NoBG{}, L0{nullptr, nb, &wf});
             SSTAMP(1)
             // output layer: g2 = (W4^T g3) * lrelu'(a2);  dW4 | db4 += g3 (x) [a2 | 1]
             if constexpr (l == 2) {
-              bwd_rows<OUTP, H>(nb, macc, g2);                                          // m += L_m (main.py:188)
+              bwd_rows<OUTP, H>(nb, macc, g2, NoBG{}, L2{&wf, nullptr, nullptr});       // m += L_m (main.py:188); a pass follows
             } else {
               const f2 g3s[1] = {f2{l == 0 ? a0.y : (is_gen[n] ? 0.f : a0.x), 0.f}};   // theta += L_theta (:182); v only without a generator (:184-186)
-              bwd_rows<2, H>(nb, g3s, g2);
+              bwd_rows<2, H>(nb, g3s, g2, NoBG{}, std::conditional_t<FOLD4, L1, L2>{&wf, nb + NL::oW2, &wf});
             }
 #pragma unroll
             for (int u = 0; u < H / 2; ++u) g2[u] = g2[u] * dlrelu2(a2[u]);
-            static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putB(rec, lane, j, a2[j]); });
-            gws_putB(rec, lane, H / 2, f2{1.f, 0.f});
-            static_for<0, NA4>([&](auto t_) {
-              constexpr int t = decltype(t_)::value;
-              if constexpr (l == 2) {
-                static_for<0, 6>([&](auto j_) { constexpr int j = decltype(j_)::value; if constexpr (6 * t + j < D / 2) gws_putA(rec, lane, j, macc[6 * t + j]); });
-              } else {
-                gws_putA(rec, lane, 0, f2{l == 0 ? a0.y : (is_gen[n] ? 0.f : a0.x), 0.f});
+            if constexpr (FOLD4 || FOLDM) {                   // parked at columns 16..26 until the last dW1 window contracts them
+              static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putB<SW>(rec, lane, 8 + j, a2[j]); });
+              gws_putB<SW>(rec, lane, 8 + H / 2, f2{1.f, 0.f});
+              if constexpr (FOLDM) {
+                static_for<0, 8>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA<SW>(rec, lane, j, macc[j]); });
+                gws_w2r(); gws_pass<SW, 16>(rec, lane, T4[0]); gws_r2w();
               }
-              gws_w2r(); gws_pass(rec, lane, T4[t]); gws_r2w();
-            });
+            } else {
+              static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putB<SW>(rec, lane, j, a2[j]); });
+              gws_putB<SW>(rec, lane, H / 2, f2{1.f, 0.f});
+              static_for<0, NA4>([&](auto t_) {
+                constexpr int t = decltype(t_)::value;
+                if constexpr (l == 2) {
+                  static_for<0, 6>([&](auto j_) { constexpr int j = decltype(j_)::value; if constexpr (6 * t + j < D / 2) gws_putA<SW>(rec, lane, j, macc[6 * t + j]); });
+                } else {
+                  gws_putA<SW>(rec, lane, 0, f2{l == 0 ? a0.y : (is_gen[n] ? 0.f : a0.x), 0.f});
+                }
+                gws_w2r(); gws_pass<SW>(rec, lane, T4[t]); gws_r2w();
+              });
+            }
             SSTAMP(2)
             // hidden layer: g1 = (W2^T g2) * lrelu'(a1);  dW2 | db2 += g2 (x) [a1 | 1]
-            bwd_rows<H, H>(nb + NL::oW2, g2, g1);
+            bwd_rows<H, H>(nb + NL::oW2, g2, g1, NoBG{}, std::conditional_t<FOLD4, L2, NoLink>{&wf, nullptr, nullptr});
 #pragma unroll
             for (int u = 0; u < H / 2; ++u) g1[u] = g1[u] * dlrelu2(a1[u]);
-            static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA(rec, lane, j, g2[j]); gws_putB(rec, lane, j, a1[j]); });
-            gws_putB(rec, lane, H / 2, f2{1.f, 0.f});
-            gws_w2r(); gws_pass(rec, lane, T2); gws_r2w();
+            static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA<SW>(rec, lane, j, g2[j]); gws_putB<SW>(rec, lane, j, a1[j]); });
+            gws_putB<SW>(rec, lane, H / 2, f2{1.f, 0.f});
+            gws_w2r(); gws_pass<SW>(rec, lane, T2); gws_r2w();
             SSTAMP(3)
             // first layer: dW1 | db1 += g1 (x) [x | 1] in 16-column windows
-            static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA(rec, lane, j, g1[j]); });
+            static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA<SW>(rec, lane, j, g1[j]); });
+            if constexpr (FOLD4) gws_putA<SW>(rec, lane, H / 2, f2{l == 0 ? a0.y : (is_gen[n] ? 0.f : a0.x), 0.f});   // row 10: g3 (theta += L_theta :182; v only without a generator :184-186)
+            if constexpr (FOLDM) static_for<0, (OUT - 16) / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA<SW>(rec, lane, H / 2 + j, macc[8 + j]); });   // rows 10..: upstream of outputs 16..d-1 (macc is still mbar_{k+1} here)
             static_for<0, NB1>([&](auto t_) {
               constexpr int t = decltype(t_)::value;
-              static_for<0, 8>([&](auto j_) { constexpr int j = decltype(j_)::value; if constexpr (8 * t + j < XL) gws_putB(rec, lane, j, xs[8 * t + j]); });
-              gws_w2r(); gws_pass(rec, lane, T1[t]); gws_r2w();
+              constexpr int po = (WIDE && t == NB1 - 1) ? W2OFF / 2 : 0;                   // the last window sits right below column 16
+              static_for<0, 8>([&](auto j_) { constexpr int j = decltype(j_)::value; if constexpr (8 * t + j < XL) gws_putB<SW>(rec, lane, po + j, xs[8 * t + j]); });
+              gws_w2r(); gws_pass<SW, (WIDE && t == NB1 - 1) ? W2OFF : 0>(rec, lane, T1[t]); gws_r2w();
             });
             SSTAMP(4)
             // input adjoints, four at a time, straight to their consumers
@@ -610,6 +644,8 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
           SSTAMP(5)
           if (p0 < p1) {                                      // back through the hidden vectors of the lines ending at n
             f2 uh[H / 2], G1[H / 2];
+            if constexpr (WIDE)                               // the latent tail, parked behind [line parameters | 1] at columns 16..21
+              static_for<0, (D - 16) / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putB<SW>(rec, lane, 8 + (PIN - D + 2) / 2 + j, m[8 + j]); });
             phi_head<D, H>(ptb, m, uh);
             SSTAMP(6)
 #pragma unroll
@@ -622,19 +658,20 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
 #endif
               const f2 xt[3] = {f2{ea.x, ea.y}, f2{ea.z, ea.w}, f2{eb.x, 0.f}};
               f2 a1[H / 2], a2[H / 2], g2[H / 2], g1[H / 2];
-              phi_tail<PIN, H, D>(ptb, uh, xt, a1, a2);
+              phi_tail<PIN, H, D>(ptb, uh, xt, a1, a2, NoBG{}, L0{nullptr, pnb, &wf});
 #pragma unroll
               for (int u = 0; u < H / 2; ++u) g2[u] = gS[u] * dlrelu2(a2[u]);
-              bwd_rows<H, H>(pnb, g2, g1);
+              bwd_rows<H, H>(pnb, g2, g1, NoBG{}, L2{&wf, nullptr, nullptr});
 #pragma unroll
               for (int u = 0; u < H / 2; ++u) { g1[u] = g1[u] * dlrelu2(a1[u]); G1[u] += g1[u]; }
               SSTAMP(7)
-              static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA(rec, lane, j, g1[j]); });
-              gws_putB(rec, lane, 0, xt[0]); gws_putB(rec, lane, 1, xt[1]); gws_putB(rec, lane, 2, f2{xt[2].x, 1.f});
-              gws_w2r(); gws_pass(rec, lane, TP1); gws_r2w();
-              static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA(rec, lane, j, g2[j]); gws_putB(rec, lane, j, a1[j]); });
-              gws_putB(rec, lane, H / 2, f2{1.f, 0.f});
-              gws_w2r(); gws_pass(rec, lane, TP2); gws_r2w();
+              constexpr int pw = WIDE ? 8 : 0;                // wide window: the line's pass contracts columns 16..31
+              static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA<SW>(rec, lane, j, g1[j]); });
+              gws_putB<SW>(rec, lane, pw + 0, xt[0]); gws_putB<SW>(rec, lane, pw + 1, xt[1]); gws_putB<SW>(rec, lane, pw + 2, f2{xt[2].x, 1.f});
+              gws_w2r(); gws_pass<SW, 2 * pw>(rec, lane, TP1); gws_r2w();
+              static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA<SW>(rec, lane, j, g2[j]); gws_putB<SW>(rec, lane, j, a1[j]); });
+              gws_putB<SW>(rec, lane, H / 2, f2{1.f, 0.f});
+              gws_w2r(); gws_pass<SW>(rec, lane, TP2); gws_r2w();
               SSTAMP(8)
             }
             // x = [m(dst) | ...] (main.py:155): d/dm += W1[:, :d]^T G1 and the latent columns of dW1 += G1 (x) m, once per bus
@@ -642,11 +679,11 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
               constexpr int ip = decltype(ip_)::value;
               if constexpr (ip < D / 2) macc[ip] += v;
             });
-            static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA(rec, lane, j, G1[j]); });
-            static_for<0, NDM>([&](auto t_) {
+            static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA<SW>(rec, lane, j, G1[j]); });
+            static_for<0, NDMF>([&](auto t_) {
               constexpr int t = decltype(t_)::value;
-              static_for<0, 8>([&](auto j_) { constexpr int j = decltype(j_)::value; if constexpr (8 * t + j < D / 2) gws_putB(rec, lane, j, m[8 * t + j]); });
-              gws_w2r(); gws_pass(rec, lane, TPm[t]); gws_r2w();
+              static_for<0, 8>([&](auto j_) { constexpr int j = decltype(j_)::value; if constexpr (8 * t + j < D / 2) gws_putB<SW>(rec, lane, j, m[8 * t + j]); });
+              gws_w2r(); gws_pass<SW>(rec, lane, TPm[t]); gws_r2w();
             });
           }
           SSTAMP(9)
@@ -658,15 +695,29 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
           constexpr int ob1 = LIN * H, oW2 = ob1 + H, ob2 = oW2 + H * H, oW4 = ob2 + H, ob4 = oW4 + OUT * H;
           float* lb_ = slab + A.g_off[C::NPHI + l] + koff * A.g_sz[C::NPHI + l];
           static_for<0, NB1>([&](auto t_) { constexpr int t = decltype(t_)::value;
-            gws_flush(lane, T1[t], lb_, [&](int c, int il) { const int i = 16 * t + il; return c < H ? (i < LIN ? c * LIN + i : (i == LIN ? ob1 + c : -1)) : -1; }, first_store); });
+            gws_flush(lane, T1[t], lb_, [&](int c, int il) {
+              const bool last = WIDE && t == NB1 - 1;                       // [x tail | a2 | 1]: the x columns end at XT
+              const int i = 16 * t + il;
+              if (c < H) return (last && il >= XT) ? -1 : (i < LIN ? c * LIN + i : (i == LIN ? ob1 + c : -1));
+              if (FOLD4 && last && c == H && il >= XT && il <= XT + H) return il - XT < H ? oW4 + (il - XT) : ob4;   // row 10 = g3: dW4 | db4 of the scalar output
+              if (FOLDM && last && c >= H && c < H + (OUT - 16) && il >= XT && il <= XT + H) { const int j = 16 + c - H; return il - XT < H ? oW4 + j * H + (il - XT) : ob4 + j; }
+              return -1; }, first_store); });
           gws_flush(lane, T2, lb_, [&](int c, int il) { return c < H ? (il < H ? oW2 + c * H + il : (il == H ? ob2 + c : -1)) : -1; }, first_store);
+          if constexpr (FOLDM)
+            gws_flush(lane, T4[0], lb_, [&](int c, int il) { return il < H ? oW4 + c * H + il : (il == H ? ob4 + c : -1); }, first_store);   // outputs 0..15
+          else if constexpr (!FOLD4)
           static_for<0, NA4>([&](auto t_) { constexpr int t = decltype(t_)::value;
             gws_flush(lane, T4[t], lb_, [&](int c, int il) { const int j = 12 * t + c; return (c < 12 && j < OUT) ? (il < H ? oW4 + j * H + il : (il == H ? ob4 + j : -1)) : -1; }, first_store); });
           constexpr int pb1 = PIN * H, pW2 = pb1 + H, pb2 = pW2 + H * H;
           float* pb_ = slab + A.g_off[fphi] + koff * A.g_sz[fphi];
-          gws_flush(lane, TP1, pb_, [&](int c, int il) { return c < H ? (il < PIN - D ? c * PIN + D + il : (il == PIN - D ? pb1 + c : -1)) : -1; }, first_store);
+          gws_flush(lane, TP1, pb_, [&](int c, int il) {
+            if (c >= H) return -1;
+            if (il < PIN - D) return c * PIN + D + il;
+            if (il == PIN - D) return pb1 + c;
+            if (WIDE && il >= PIN - D + 1 && il < PIN - D + 1 + (D - 16)) return c * PIN + 16 + (il - (PIN - D + 1));   // latent tail m[16..D)
+            return -1; }, first_store);
           gws_flush(lane, TP2, pb_, [&](int c, int il) { return c < H ? (il < H ? pW2 + c * H + il : (il == H ? pb2 + c : -1)) : -1; }, first_store);
-          static_for<0, NDM>([&](auto t_) { constexpr int t = decltype(t_)::value;
+          static_for<0, NDMF>([&](auto t_) { constexpr int t = decltype(t_)::value;
             gws_flush(lane, TPm[t], pb_, [&](int c, int il) { const int i = 16 * t + il; return (c < H && i < D) ? c * PIN + i : -1; }, first_store); });
         }
         STAMP(5 + l)

@@ -112,14 +112,41 @@ __device__ __forceinline__ void touch(const f16v& v) { asm volatile("" ::"s"(v[0
 // keeps both pipes busy from ONE wave (gns_dw.h, GwDrain).
 struct NoBG { template <int S> __device__ __forceinline__ void slot() {} };
 
-template <int NF, class VP = cf16p, class F, class BG = NoBG>
-__device__ __forceinline__ void stream_pairs(cfp p, F&& f, BG&& bg = BG{}) {
+// Links between consecutive weight streams.  A stream's first 32 floats cost a full scalar-cache round trip before its first
+// FMA (measured: 0.18 ms of the 2.6 ms backward, gns_device.h GNS_ABLATE_SLOAD_ALL).  A linked stream fetches the first chunk
+// of the NEXT stream in its own last step - into the half of its double buffer that is idle by then, so no extra SGPRs while
+// it runs - and hands it over; the next stream starts from those registers.
+struct WFirst { f16v a0, a1; };
+template <class VP = cf16p>
+__device__ __forceinline__ void stream_first(cfp p, WFirst& w) { p += opaque_zero(); w.a0 = *(VP)(p); w.a1 = *(VP)(p + 16); }
+template <bool PRE_, bool NXT_, class NVP_ = cf16p>
+struct WLink {
+  static constexpr bool PRE = PRE_, NXT = NXT_;
+  using NVP = NVP_;
+  const WFirst* pre;      // PRE: this stream's first chunk, fetched ahead
+  cfp next;               // NXT: where the next stream starts
+  WFirst* nxt;            //      and where its first chunk goes
+};
+using NoLink = WLink<false, false>;
+
+template <int NF, class VP = cf16p, class F, class BG = NoBG, class LK = NoLink>
+__device__ __forceinline__ void stream_pairs(cfp p, F&& f, BG&& bg = BG{}, LK lk = LK{}) {
   // 32-float steps: two s_load_dwordx16 are in flight while the previous 32 floats feed 16 packed FMAs
   constexpr int NST = (NF + 31) / 32;
   p += opaque_zero();
   f16v a0, a1, b0, b1;
-  a0 = *(VP)(p);
-  a1 = *(VP)(p + 16);
+#ifdef GNS_ABLATE_SLOAD_ALL   // diagnostic: no scalar load at all, not even a stream's first chunk (wrong numbers; what ALL weight fetches cost)
+  {
+    int zi = 0;
+    asm volatile("" : "+s"(zi));
+    const float z = __builtin_bit_cast(float, zi);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { a0[i] = z; a1[i] = z; }
+  }
+#else
+  if constexpr (LK::PRE) { a0 = lk.pre->a0; a1 = lk.pre->a1; }
+  else { a0 = *(VP)(p); a1 = *(VP)(p + 16); }
+#endif
   static_for<0, NST>([&](auto c_) {
     constexpr int c = decltype(c_)::value;
     f16v& c0 = (c & 1) ? b0 : a0;
@@ -128,12 +155,16 @@ __device__ __forceinline__ void stream_pairs(cfp p, F&& f, BG&& bg = BG{}) {
     f16v& n1 = (c & 1) ? a1 : b1;
     touch(c0);
     touch(c1);
-#ifdef GNS_ABLATE_SLOAD   // diagnostic: the stream keeps re-using its first 32 floats (wrong numbers, no scalar-load latency)
+#if defined(GNS_ABLATE_SLOAD) || defined(GNS_ABLATE_SLOAD_ALL)   // diagnostic: the stream keeps re-using its first 32 floats (wrong numbers, no scalar-load latency)
     if constexpr (c + 1 < NST) { n0 = c0; n1 = c1; }
 #else
     if constexpr (c + 1 < NST) {
       n0 = *(VP)(p + 32 * (c + 1));
       n1 = *(VP)(p + 32 * (c + 1) + 16);
+    } else if constexpr (LK::NXT) {
+      cfp q = lk.next + opaque_zero();
+      n0 = *(typename LK::NVP)(q);
+      n1 = *(typename LK::NVP)(q + 16);
     }
 #endif
     __builtin_amdgcn_sched_barrier(0);
@@ -151,6 +182,12 @@ __device__ __forceinline__ void stream_pairs(cfp p, F&& f, BG&& bg = BG{}) {
     });
     __builtin_amdgcn_sched_barrier(0);
   });
+#if !defined(GNS_ABLATE_SLOAD) && !defined(GNS_ABLATE_SLOAD_ALL)
+  if constexpr (LK::NXT) {
+    lk.nxt->a0 = ((NST - 1) & 1) ? a0 : b0;
+    lk.nxt->a1 = ((NST - 1) & 1) ? a1 : b1;
+  }
+#endif
 }
 
 // Pin a value to the point where it was computed.  MachineSink otherwise moves a whole LearningBlock's FMAs down
@@ -258,8 +295,8 @@ struct TLay2 {
   static constexpr int ob1 = IN * H, oW2 = ob1 + H, ob2 = oW2 + H * H, total = ob2 + H;
 };
 
-template <int IN, int H, class BG = NoBG>
-__device__ __forceinline__ void mlp2_fwd(cfp blk, const f2 (&x)[(IN + 1) / 2], f2 (&a1)[H / 2], f2 (&a2)[H / 2], BG&& bg = BG{}) {
+template <int IN, int H, class BG = NoBG, class LK = NoLink>
+__device__ __forceinline__ void mlp2_fwd(cfp blk, const f2 (&x)[(IN + 1) / 2], f2 (&a1)[H / 2], f2 (&a2)[H / 2], BG&& bg = BG{}, LK lk = LK{}) {
   using B = TLay2<IN, H>;
   stream_pairs<B::total, cf16p>(blk, [&](auto w_, f2 s) {
     constexpr int w = decltype(w_)::value;
@@ -278,7 +315,7 @@ __device__ __forceinline__ void mlp2_fwd(cfp blk, const f2 (&x)[(IN + 1) / 2], f
       constexpr int j = (w - B::ob2) / 2;
       a2[j] = lrelu2(a2[j] + s);
     }
-  }, bg);
+  }, bg, lk);
   pin_all(a2);
 }
 
@@ -286,17 +323,17 @@ __device__ __forceinline__ void mlp2_fwd(cfp blk, const f2 (&x)[(IN + 1) / 2], f
 // rows of W1t - 200 of the 370 streamed floats - give the same partial sums u for all of them: phi_head once per bus,
 // phi_tail (the 5 line parameters, b1, layer 2) once per line.  The accumulation order is that of mlp2_fwd
 // (inputs 0..D-1, then D..IN-1, then the bias), so a1, a2 are bitwise the same.
-template <int D, int H, class BG = NoBG>
-__device__ __forceinline__ void phi_head(cfp blk, const f2 (&m)[D / 2], f2 (&u)[H / 2], BG&& bg = BG{}) {
+template <int D, int H, class BG = NoBG, class LK = NoLink>
+__device__ __forceinline__ void phi_head(cfp blk, const f2 (&m)[D / 2], f2 (&u)[H / 2], BG&& bg = BG{}, LK lk = LK{}) {
   stream_pairs<D * H, cf16p>(blk, [&](auto w_, f2 s) {
     constexpr int w = decltype(w_)::value, i = w / H, j = (w % H) / 2;
     const f2 xi = splat(lane_of<i>(m));
     u[j] = (i == 0) ? s * xi : __builtin_elementwise_fma(s, xi, u[j]);
-  }, bg);
+  }, bg, lk);
   pin_all(u);
 }
-template <int IN, int H, int D, class BG = NoBG>
-__device__ __forceinline__ void phi_tail(cfp blk, const f2 (&u)[H / 2], const f2 (&xt)[(IN - D + 1) / 2], f2 (&a1)[H / 2], f2 (&a2)[H / 2], BG&& bg = BG{}) {
+template <int IN, int H, int D, class BG = NoBG, class LK = NoLink>
+__device__ __forceinline__ void phi_tail(cfp blk, const f2 (&u)[H / 2], const f2 (&xt)[(IN - D + 1) / 2], f2 (&a1)[H / 2], f2 (&a2)[H / 2], BG&& bg = BG{}, LK lk = LK{}) {
   using B = TLay2<IN, H>;
   constexpr int W0 = D * H;
 #pragma unroll
@@ -318,7 +355,7 @@ __device__ __forceinline__ void phi_tail(cfp blk, const f2 (&u)[H / 2], const f2
       constexpr int j = (w - B::ob2) / 2;
       a2[j] = lrelu2(a2[j] + s);
     }
-  }, bg);
+  }, bg, lk);
   pin_all(a2);
 }
 
@@ -358,18 +395,18 @@ __device__ __forceinline__ void mlp2_bwd(cfp blk, const f2 (&a1)[H / 2], const f
 
 // ---- layer-wise data path of the backward (used where each layer's weight gradient is contracted as soon as its operands exist) ----
 // gout[i] = sum_j Wn[j][i] gin[j] from an [NJ][H] stream (output layer and hidden layer of the data path)
-template <int NJP, int H, class BG = NoBG>
-__device__ __forceinline__ void bwd_rows(cfp blk, const f2 (&gin)[NJP / 2], f2 (&gout)[H / 2], BG&& bg = BG{}) {
+template <int NJP, int H, class BG = NoBG, class LK = NoLink>
+__device__ __forceinline__ void bwd_rows(cfp blk, const f2 (&gin)[NJP / 2], f2 (&gout)[H / 2], BG&& bg = BG{}, LK lk = LK{}) {
   stream_pairs<NJP * H, cf16p>(blk, [&](auto w_, f2 s) {
     constexpr int w = decltype(w_)::value, j = w / H, i = (w % H) / 2;
     const f2 gj = splat(lane_of<j>(gin));
     gout[i] = (j == 0) ? s * gj : __builtin_elementwise_fma(s, gj, gout[i]);
-  }, bg);
+  }, bg, lk);
   pin_all(gout);
 }
 // Input adjoints from the input-major stream W1x[NG][H][4]: four inputs at a time, each finished pair handed to sink(ic<pair>, value)
-template <int NG, int H, class F, class BG = NoBG>
-__device__ __forceinline__ void bwd_inputs(cfp blk, const f2 (&g1)[H / 2], F&& sink, BG&& bg = BG{}) {
+template <int NG, int H, class F, class BG = NoBG, class LK = NoLink>
+__device__ __forceinline__ void bwd_inputs(cfp blk, const f2 (&g1)[H / 2], F&& sink, BG&& bg = BG{}, LK lk = LK{}) {
   f2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
   stream_pairs<NG * H * 4, cf16p>(blk, [&](auto w_, f2 s) {
     constexpr int w = decltype(w_)::value, g = w / (4 * H), r = w % (4 * H), j = r / 4, half = (r % 4) / 2;
@@ -381,7 +418,7 @@ __device__ __forceinline__ void bwd_inputs(cfp blk, const f2 (&g1)[H / 2], F&& s
       sink(std::integral_constant<int, 2 * g>{}, acc0);
       sink(std::integral_constant<int, 2 * g + 1>{}, acc1);
     }
-  }, bg);
+  }, bg, lk);
 }
 
 // float4-row addressing: [row][lane] with 16 B per lane -> every wave access is one contiguous 1 KiB

@@ -538,31 +538,42 @@ struct GwBusPhiEngine {    // record [m (D, padded to 4) | G1 | 0 0 (12)]: dW1[:
 struct GwSub {
   static constexpr int NA = 12, NB = 16, RS = NA + NB, RECF = 64 * RS + 32;   // RS = 28 = 4 (mod 8): see LEngine's row map
 };
+// The same window with a 32-column B block: a pass contracts 16 CONSECUTIVE B columns starting at any column, so fields that
+// outlive a pass (the output-layer activations, the latent tail of a bus) are parked beside the columns other passes rewrite
+// and small products ride along in the spare rows / columns of a pass that is issued anyway (gns_backward.hip, V2 sweep).
+struct GwSubWide {
+#ifdef GNS_NO_FOLDM
+  static constexpr int NA = 12, NB = 32, RS = NA + NB, RECF = 64 * RS + 32;   // RS = 44 = 4 (mod 8)
+#else
+  static constexpr int NA = 16, NB = 36, RS = NA + NB, RECF = 64 * RS + 32;   // all 16 rows of the tile; RS = 52 = 4 (mod 8); B columns 32..35 pad
+#endif
+};
 __device__ __forceinline__ void gws_w2r() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 __device__ __forceinline__ void gws_r2w() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 #ifdef GNS_ABLATE_REC
-__device__ __forceinline__ void gws_putA(float* rec, int lane, int pair, f2 v) { asm volatile("" :: "v"(v)); }
-__device__ __forceinline__ void gws_putB(float* rec, int lane, int pair, f2 v) { asm volatile("" :: "v"(v)); }
+template <class S = GwSub> __device__ __forceinline__ void gws_putA(float* rec, int lane, int pair, f2 v) { asm volatile("" :: "v"(v)); }
+template <class S = GwSub> __device__ __forceinline__ void gws_putB(float* rec, int lane, int pair, f2 v) { asm volatile("" :: "v"(v)); }
 #else
-__device__ __forceinline__ void gws_putA(float* rec, int lane, int pair, f2 v) { reinterpret_cast<f2*>(rec + lane * GwSub::RS)[pair] = v; }
-__device__ __forceinline__ void gws_putB(float* rec, int lane, int pair, f2 v) { reinterpret_cast<f2*>(rec + lane * GwSub::RS + GwSub::NA)[pair] = v; }
+template <class S = GwSub> __device__ __forceinline__ void gws_putA(float* rec, int lane, int pair, f2 v) { reinterpret_cast<f2*>(rec + lane * S::RS)[pair] = v; }
+template <class S = GwSub> __device__ __forceinline__ void gws_putB(float* rec, int lane, int pair, f2 v) { reinterpret_cast<f2*>(rec + lane * S::RS + S::NA)[pair] = v; }
 #endif
 // One contraction pass over the window, in two halves of 8 k-steps (16 operand registers in flight instead of 32)
+template <class S = GwSub, int BOFF = 0>      // BOFF: first B column of the 16 this pass contracts
 __device__ __forceinline__ void gws_pass(const float* rec, int lane, f32x4& Dt) {
 #ifdef GNS_ABLATE_PASS
   asm volatile("" : "+v"(Dt));
   return;
 #endif
-  const float* base = rec + (((lane >> 5) & 1) + 4 * ((lane >> 4) & 1)) * GwSub::RS + (lane & 15);
+  const float* base = rec + (((lane >> 5) & 1) + 4 * ((lane >> 4) & 1)) * S::RS + (lane & 15);
 #ifdef GNS_PASS_HALVES          // the round-2 schedule: operands of 8 k-steps, their 8 MFMAs, twice
   static_for<0, 2>([&](auto h_) {
     constexpr int hh = decltype(h_)::value;
     float Aop[8], Bop[8];
     static_for<0, 8>([&](auto kk_) {
       constexpr int kk = 8 * hh + decltype(kk_)::value;
-      const float* b = base + (8 * (kk >> 1) + 2 * (kk & 1)) * GwSub::RS;
+      const float* b = base + (8 * (kk >> 1) + 2 * (kk & 1)) * S::RS;
       Aop[kk - 8 * hh] = b[0];
-      Bop[kk - 8 * hh] = b[GwSub::NA];
+      Bop[kk - 8 * hh] = b[S::NA + BOFF];
     });
     static_for<0, 8>([&](auto kk_) {
       constexpr int kk = decltype(kk_)::value;
@@ -580,9 +591,9 @@ __device__ __forceinline__ void gws_pass(const float* rec, int lane, f32x4& Dt) 
   float Aop[AH], Bop[AH];
   auto rd = [&](auto kk_) {
     constexpr int kk = decltype(kk_)::value;
-    const float* b = base + (8 * (kk >> 1) + 2 * (kk & 1)) * GwSub::RS;
+    const float* b = base + (8 * (kk >> 1) + 2 * (kk & 1)) * S::RS;
     Aop[kk % AH] = b[0];
-    Bop[kk % AH] = b[GwSub::NA];
+    Bop[kk % AH] = b[S::NA + BOFF];
   };
   static_for<0, AH>([&](auto kk_) { rd(kk_); });
   __builtin_amdgcn_sched_barrier(0);
