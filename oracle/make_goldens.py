@@ -139,11 +139,60 @@ def run_prepare(synth, name, case_nr, batch, seed):
     print(f'{name}: wrote {os.path.getsize(path) / 1024:.0f} KiB')
 
 
+def run_metrics(name, n_samples, n_bus, n_line, seed):
+    """Goldens for the evaluation metrics.  ``GNS/evaluate.py`` is a module-level script that needs PYPOWER,
+    unshipped grids and an unshipped checkpoint, so it cannot be imported; what CAN be executed are its own statements:
+    the file is parsed (never copied), the ``active_line_flow`` function (``evaluate.py:15-18``) and the module-level
+    assignments that compute the error statistics from the six result arrays (``evaluate.py:93-125,150-156``: only ``np``
+    calls on those arrays) are compiled from the parsed tree and run on synthetic solver / Newton-Raphson results."""
+    import ast
+    src = open(os.path.join(REF, 'evaluate.py')).read()
+    tree = ast.parse(src)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == 'active_line_flow']
+    assert len(fn) == 1
+    inputs = {'NR_theta_out', 'GNS_theta_out', 'NR_v_out', 'GNS_v_out', 'NR_active_line_flow', 'GNS_active_line_flow'}
+    known = set(inputs) | {'np', 'int'}
+    stats = []
+    for n in tree.body:
+        if not isinstance(n, ast.Assign) or n.lineno < 93:
+            continue
+        names = {x.id for x in ast.walk(n.value) if isinstance(x, ast.Name)}
+        if names and names <= known and len(n.targets) == 1 and isinstance(n.targets[0], ast.Name):
+            stats.append(n)
+            known.add(n.targets[0].id)
+    ns = {'np': np}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), 'evaluate.py', 'exec'), ns)
+    rng = np.random.default_rng(seed)
+    v_nr = rng.uniform(0.94, 1.06, (n_samples, n_bus)).astype(np.float32)
+    th_nr_deg = rng.uniform(-25.0, 25.0, (n_samples, n_bus)).astype(np.float32)      # PYPOWER reports degrees (evaluate.py:94)
+    v_gns = (v_nr * rng.uniform(0.98, 1.02, v_nr.shape)).astype(np.float32)
+    th_gns = (np.deg2rad(th_nr_deg) + rng.normal(0, 0.02, v_nr.shape)).astype(np.float32)
+    src_bus = rng.integers(1, n_bus + 1, n_line).astype(np.float64)
+    dst_bus = ((src_bus - 1 + rng.integers(1, n_bus, n_line)) % n_bus + 1).astype(np.float64)
+    x = rng.uniform(0.02, 0.3, (n_samples, n_line))
+    alf = ns['active_line_flow']
+    alf_nr = np.stack([alf(v_nr[i], np.deg2rad(th_nr_deg[i]), x[i], src_bus, dst_bus) for i in range(n_samples)]).astype(np.float32)
+    alf_gns = np.stack([alf(v_gns[i], th_gns[i], x[i], src_bus, dst_bus) for i in range(n_samples)]).astype(np.float32)
+    ns.update(NR_theta_out=th_nr_deg.copy(), GNS_theta_out=th_gns.copy(), NR_v_out=v_nr.copy(), GNS_v_out=v_gns.copy(),
+              NR_active_line_flow=alf_nr.copy(), GNS_active_line_flow=alf_gns.copy())
+    exec(compile(ast.Module(body=stats, type_ignores=[]), 'evaluate.py', 'exec'), ns)
+    out = {'in_v_nr': v_nr, 'in_theta_nr_deg': th_nr_deg, 'in_v_gns': v_gns, 'in_theta_gns': th_gns, 'in_x': x,
+           'in_src': src_bus, 'in_dst': dst_bus, 'alf_nr': alf_nr, 'alf_gns': alf_gns,
+           'stat_lines': np.array([n.lineno for n in stats])}
+    for n in stats:
+        k = n.targets[0].id
+        if k not in inputs:
+            out['ref_' + k] = np.asarray(ns[k])
+    np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', name + '.npz'), **out)
+    print(name, 'statements', [n.lineno for n in stats], sorted(k for k in out if k.startswith('ref_')))
+
+
 def main():
     ref = _import_reference()
     synth = _load_pkg()
     run_prepare(synth, 'prepare_c14_b4', 14, 4, 21)
     run_prepare(synth, 'prepare_c118_b2', 118, 2, 22)
+    run_metrics('metrics_c14_s64', 64, 14, 20, 31)
     os.makedirs(os.path.join(ROOT, 'tests', 'golden'), exist_ok=True)
     # name, case, batch, K, d, h, multi, seed, load_scale
     cases = [

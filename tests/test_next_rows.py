@@ -48,6 +48,44 @@ def test_active_line_flow_and_percentiles_against_numpy_restatement():
     np.testing.assert_allclose(float(e['theta_abs_std']), np.std(np.abs(th - (th + 0.01))), rtol=1e-6, atol=1e-12)
 
 
+def _check_metrics_against_reference_statements(dev):
+    """f4 pinned: the expected values were produced by the reference's OWN statements (``evaluate.py:15-18`` and the
+    statistics assignments of ``evaluate.py:93-157``, compiled from the parsed file by ``oracle/make_goldens.py``)."""
+    g = load_golden('metrics_c14_s64')
+    dt = lambda a: torch.as_tensor(np.asarray(a)).to(dev)
+    v_nr, th_nr = dt(g['in_v_nr']), torch.deg2rad(dt(g['in_theta_nr_deg']))
+    v, th = dt(g['in_v_gns']), dt(g['in_theta_gns'])
+    f_nr = amd.metrics.active_line_flow(v_nr.double(), th_nr.double(), dt(g['in_x']), dt(g['in_src']), dt(g['in_dst']))
+    f = amd.metrics.active_line_flow(v.double(), th.double(), dt(g['in_x']), dt(g['in_src']), dt(g['in_dst']))
+    np.testing.assert_allclose(f_nr.cpu().numpy(), g['alf_nr'], rtol=2e-6, atol=1e-7)       # the reference stores float32
+    np.testing.assert_allclose(f.cpu().numpy(), g['alf_gns'], rtol=2e-6, atol=1e-7)
+    e = amd.metrics.solution_errors(v, th, v_nr, th_nr)
+    c = lambda x: x.detach().cpu().numpy()
+    np.testing.assert_allclose(c(e['theta_abs_mean']), g['ref_mean_diff_theta_gns'], rtol=1e-5)
+    np.testing.assert_allclose(c(e['theta_abs_std']), g['ref_std_diff_theta_gns'], rtol=1e-4)
+    np.testing.assert_allclose(c(e['v_abs_mean']), g['ref_mean_diff_v_gns'], rtol=1e-5)
+    np.testing.assert_allclose(c(e['v_abs_std']), g['ref_std_diff_v_gns'], rtol=1e-4)
+    np.testing.assert_allclose(c(e['theta_pct_error']), g['ref_theta_error_gns_nr'], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(c(e['v_pct_error']), g['ref_v_error_gns_nr'], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(c(e['v_diff_per_bus_mean']), g['ref_mean_diffs_v'], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(c(e['v_diff_per_bus_std']), g['ref_std_diffs_v'], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(c(e['theta_diff_per_bus_mean']), g['ref_mean_diffs_theta'], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(c(e['theta_diff_per_bus_std']), g['ref_std_diffs_theta'], rtol=1e-4, atol=1e-7)
+    q = amd.metrics.line_flow_percentiles(dt(g['alf_gns']), dt(g['alf_nr']))
+    np.testing.assert_allclose([float(q['p20']), float(q['median']), float(q['p80'])],
+                               [float(g['ref_twenty_percentile_diff_alf_gns_nr']), float(g['ref_median_diff_alf_gns_nr']),
+                                float(g['ref_eighty_percentile_diff_alf_gns_nr'])], rtol=1e-5)
+
+
+def test_metrics_match_the_reference_evaluation_statements():
+    _check_metrics_against_reference_statements('cpu')
+
+
+@pytest.mark.gpu
+def test_metrics_match_the_reference_evaluation_statements_on_the_device():
+    _check_metrics_against_reference_statements('cuda')
+
+
 class _FakeGNS(torch.nn.Module):
     """Stands in for the GPU model in the CPU test of the loop logic: loss follows a scripted sequence per epoch."""
 
