@@ -244,7 +244,11 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
       STAMP(3)
 
       // ---------------- Ub, pass G: every bus completes d/d(v,theta)_{k+1} from the per-line adjoints --------------
+#ifdef GNS_ABLATE_GATHER
+      for (int n = n0; n < n0; ++n) {
+#else
       for (int n = n0; n < n1; ++n) {
+#endif
         const long long ar = adj_row(n);
         const f4 a0 = *row_ptr(A.adj, ar, lane);
         const f4 s1 = *row_ptr(A.state, state_row(k + 1, n), lane);         // issued with the list loads below, used after them

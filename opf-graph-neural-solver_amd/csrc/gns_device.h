@@ -422,10 +422,35 @@ __device__ __forceinline__ void bwd_inputs(cfp blk, const f2 (&g1)[H / 2], F&& s
 }
 
 // float4-row addressing: [row][lane] with 16 B per lane -> every wave access is one contiguous 1 KiB
+// The row base (wave-uniform) is pinned to a scalar register pair and the lane contributes one 32-bit byte offset, so that an
+// access is `global_load_dwordx4 v, v_off, s[base:base+1]`: hipcc otherwise folds the lane into a 64-bit per-lane address
+// (v_lshl_add_u64 / v_mad_u64_u32 per access and a VGPR pair per live address).  Measured (round 2, -DGNS_ROW_SADDR=1): the
+// forward drops to 125 VGPRs with no scratch and the backward to 25 spilled VGPRs, yet both are 3 % SLOWER (1.04 vs 1.00 ms,
+// 2.73 vs 2.66 ms): the scalar address chain sits in front of every load and costs 40 more spilled SGPRs.  Off by default.
+#ifndef GNS_ROW_SADDR
+#define GNS_ROW_SADDR 0
+#endif
 __device__ __forceinline__ const f4* row_ptr(const float* base, long long row, int lane) {
+#if GNS_ROW_SADDR
+  const char* p = reinterpret_cast<const char*>(base) + row * (GNS_LANES * 16);
+  asm("" : "+s"(p));
+  return reinterpret_cast<const f4*>(p + (unsigned)(lane * 16));
+#else
   return reinterpret_cast<const f4*>(base) + row * GNS_LANES + lane;
+#endif
 }
 __device__ __forceinline__ f4* row_ptr(float* base, long long row, int lane) {
+#if GNS_ROW_SADDR
+  char* p = reinterpret_cast<char*>(base) + row * (GNS_LANES * 16);
+  asm("" : "+s"(p));
+  return reinterpret_cast<f4*>(p + (unsigned)(lane * 16));
+#else
+  return reinterpret_cast<f4*>(base) + row * GNS_LANES + lane;
+#endif
+}
+
+// per-lane rows (the input packing kernel: a thread picks its own row)
+__device__ __forceinline__ f4* row_ptr_lanewise(float* base, long long row, int lane) {
   return reinterpret_cast<f4*>(base) + row * GNS_LANES + lane;
 }
 

@@ -109,7 +109,7 @@ __global__ void gns_pack_inputs_kernel(const int* __restrict__ topo, const float
     return __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(__fmul_rn(r, r), __fmul_rn(x, x))));
   };
   float* og = out + g * rows * (GNS_LANES * 4);
-  auto put = [&](long long row, const f4& o) { *row_ptr(og, row, lane) = o; };
+  auto put = [&](long long row, const f4& o) { *row_ptr_lanewise(og, row, lane) = o; };
 
   if (c < cb) {                                                     // ---- bus n: rows 3n .. 3n+2
     const int n = c * W + wave;
