@@ -18,6 +18,12 @@
 #include "gns_dw.h"
 
 
+
+#ifndef GNS_BWD_PLANES
+#define GNS_BWD_PLANES 1
+#endif
+typedef int gns_i8v __attribute__((ext_vector_type(8)));
+
 // ------------------------------------------------------------------------------------------------
 // V2 (three phi nets, matrix-pipe engine): the family sweep runs the layer-wise data path - each layer's weight gradient is
 // contracted through a 7 KB sub-record window as soon as its operands exist (half the LDS stores of the wide half-wave
@@ -67,6 +73,16 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
   __syncthreads();                                   // team_failed is initialised
   team_setup(team, reinterpret_cast<unsigned*>(A.team_ws + (long long)team_id * GNS_TEAM_CTR_BYTES));
   float* rec = rec_all[wave];
+  // Line phase (Pb-edge): v, theta of the step being reversed and the adjoint of delta_p for every bus of the 64 grids, as
+  // three [N][64] planes over the record windows (idle outside the family sweeps).  A line gathers 6 buses' theta, 2 buses'
+  // v and 2 buses' adjoint: 10 LDS words instead of 8 HBM/L2 rows of 1 KiB of which 4-8 bytes per lane were used - those
+  // gathers were 2/3 of the phase's traffic and the phase is bound by exactly that traffic (profiles/r02/ablation_backward_v2.txt).
+  // One workgroup per group only (a team member sees only its own buses) and N <= 140 for 8 windows of 13 KiB.
+  constexpr bool PLANES = GNS_BWD_PLANES != 0;
+  const bool use_plane = PLANES && tsize == 1 && 3LL * N * GNS_LANES <= (long long)W * RECF;
+  float* const pl_v = &rec_all[0][0];
+  float* const pl_th = pl_v + (use_plane ? N * GNS_LANES : 0);
+  float* const pl_dp = pl_th + (use_plane ? N * GNS_LANES : 0);
   float* slab = A.slab + ((long long)blockIdx.x * W + wave) * A.slab_floats;
   const float invN = 1.0f / (float)N;
 
@@ -137,6 +153,7 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
       const bool low1 = bits & 1, low2 = bits & 2;
 
       // ---------------- Pb-0 (also closes step k+1: identity paths + the input adjoints its sweeps collected) --------
+      if (use_plane) __syncthreads();                      // every wave has left the sweeps: the record windows become the planes
       float lb = 0.f;
       for (int nb = n0; nb < n1; nb += 4) {                                  // four buses per round: 16 independent row loads in flight
         f4 s1[4], a0[4], xs[4], b1[4];
@@ -162,6 +179,7 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
             }
             a.z = a.z + cdp * s1[j].z;
             *row_ptr(A.adj, ar, lane) = a;
+            if (use_plane) { pl_v[n * GNS_LANES + lane] = s1[j].x; pl_th[n * GNS_LANES + lane] = s1[j].y; pl_dp[n * GNS_LANES + lane] = a.z; }
             lb += a.z * (low2 ? 2.f * (b1[j].y - b1[j].x) : 2.f * (b1[j].z - b1[j].y));    // d Pg_new / d lambda  (main.py:53-57)
           }
         }
@@ -184,10 +202,21 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
       // Two lines per iteration: the 24 loads of both are issued before either is used (the phase waits on loads, not
       // on the VALU, and a wave has only one partner on its SIMD to hide them).
       struct EdgeIn { f4 e1v, o0, ss, st; float tha, thb, thc, thd, Fb, Tb; };
+      const cip erec = topo + topo[TH_EREC];
       auto edge_load = [&](int p, EdgeIn& L) {
-        const int s = in_src[p], t = in_dst[p], ia = in_a[p], ib = in_b[p], q = p2q[p], ic = out_c[q], id = out_d[q];
+        // (s, t, a, b, q, c, d) of the line in one 32-byte scalar load (gns_topology.cpp)
+        const gns_i8v r = *reinterpret_cast<const __attribute__((address_space(4))) gns_i8v*>(erec + 8 * p);
+        const int s = r[0], t = r[1], ia = r[2], ib = r[3], q = r[4], ic = r[5], id = r[6];
         L.e1v = *row_ptr(IN, row_ein + 3LL * p + 1, lane);                  // shift_e, y_s, tau_s, sh_s
         L.o0 = *row_ptr(IN, row_eout + q, lane);                             // y_t, tau_t, sh_t, b_t
+        if (use_plane) {
+          L.ss = f4{pl_v[s * GNS_LANES + lane], pl_th[s * GNS_LANES + lane], 0.f, 0.f};
+          L.st = f4{pl_v[t * GNS_LANES + lane], pl_th[t * GNS_LANES + lane], 0.f, 0.f};
+          L.tha = pl_th[ia * GNS_LANES + lane]; L.thb = pl_th[ib * GNS_LANES + lane];
+          L.thc = pl_th[ic * GNS_LANES + lane]; L.thd = pl_th[id * GNS_LANES + lane];
+          L.Fb = pl_dp[t * GNS_LANES + lane]; L.Tb = pl_dp[s * GNS_LANES + lane];
+          return;
+        }
         L.ss = *row_ptr(A.state, state_row(k + 1, s), lane); L.st = *row_ptr(A.state, state_row(k + 1, t), lane);
         L.tha = row_ptr(A.state, state_row(k + 1, ia), lane)->y; L.thb = row_ptr(A.state, state_row(k + 1, ib), lane)->y;
         L.thc = row_ptr(A.state, state_row(k + 1, ic), lane)->y; L.thd = row_ptr(A.state, state_row(k + 1, id), lane)->y;
@@ -201,11 +230,16 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
         const float ys = e1v.y, taus = e1v.z, shs = e1v.w;
         const float dl = L.tha - L.thb, dl2 = L.thd - L.thc;
         float sA, cA, sB, cB, sD, cD, sC, cC, sD2, cD2;
+#ifdef GNS_ABLATE_PHYS_TRIG       // diagnostic: no trigonometric evaluation (results wrong by design)
+        sA = ths - tht - dl - shs; cA = 1.f - sA; sB = tht - ths - dl + shs; cB = 1.f - sB; sD = dl; cD = 1.f - dl;
+        sC = tht - ths - dl2 - o0.z; cC = 1.f - sC; sD2 = dl2; cD2 = 1.f - dl2;
+#else
         sincosf(ths - tht - dl - shs, &sA, &cA);
         sincosf(tht - ths - dl + shs, &sB, &cB);
         sincosf(dl, &sD, &cD);
         sincosf(tht - ths - dl2 - o0.z, &sC, &cC);
         sincosf(dl2, &sD2, &cD2);
+#endif
         // "from" expressions: p_from (main.py:91) and |msg| of the joule loss (main.py:41)
         const float yot = ys / taus, yot2 = ys / (taus * taus);
         const float base = vs * vt * yot;
@@ -225,8 +259,12 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
         const float Cb = Tb * base2 * cC;
         const float dbar2 = Tb * vt * vt * o0.x * cD2 - Cb;
         dtht += Cb; dths -= Cb;
+#ifdef GNS_ABLATE_PHYS_STORE      // diagnostic: the six results are computed but not stored
+        asm volatile("" :: "v"(dvs), "v"(dvt), "v"(dths), "v"(dtht), "v"(dbar), "v"(dbar2));
+#else
         *slot_ptr(0, p) = dvs; *slot_ptr(1, p) = dvt; *slot_ptr(2, p) = dths; *slot_ptr(3, p) = dtht;
         *slot_ptr(4, p) = dbar; *slot_ptr(5, p) = dbar2;
+#endif
       };
 #ifdef GNS_ABLATE_PHYS
       for (int p = e0; p < e0; p += 2) {

@@ -17,7 +17,7 @@
 #endif
 
 #define GNS_LANES 64
-#define GNS_TOPO_MAGIC 0x474e5331  // "GNS1"
+#define GNS_TOPO_MAGIC 0x474e5332  // "GNS2"
 #define GNS_NPART 6                // bus partitions are stored for 1,2,4,8,16,32 waves per 64-grid group
 #define GNS_MAXW 16                // waves of ONE workgroup (sizes the LDS reduction buffers)
 #define GNS_MAXP 32                // waves of one 64-grid group: up to GNS_MAX_TEAM workgroups share a group (gns_device.h, "teams")
@@ -50,6 +50,7 @@ enum {
   TH_PPART,     // [GNS_NPART][GNS_MAXP+1] forward physics phase: bus ranges balanced by incident lines
   TH_LANE_BUS,  // [N]   grid-per-workgroup mapping: bus handled by bus lane i (buses in descending in-degree order, so the
                 //       lanes of one wave run similar trip counts in their incidence loops)
+  TH_EREC,      // [E][8]  backward line phase: (s, t, a, b, q, c, d, 0) of in-edge p in one 32-byte record (one scalar load instead of seven)
   TH_TOTAL,     // blob length in words
   TH_HDR_WORDS = 32
 };

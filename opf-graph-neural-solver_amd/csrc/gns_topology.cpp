@@ -121,6 +121,16 @@ int build(int N, int E, int Gn, const int32_t* src, const int32_t* dst, const in
   b.put(TH_PART, part); b.put(TH_P2Q, p2q); b.put(TH_Q2P, q2p); b.put(TH_EPART, epart);
   b.put(TH_INCD_PTR, incd_ptr); b.put(TH_INCD, incd); b.put(TH_IN_DST, in_dst);
   b.put(TH_UPART, upart); b.put(TH_PPART, ppart);
+  {   // one-load record of the backward's line phase (64-byte aligned in the blob)
+    std::vector<int32_t> erec(8 * (size_t)E, 0);
+    for (int p = 0; p < E; ++p) {
+      const int q = p2q[p];
+      const int32_t r[8] = {in_src[p], in_dst[p], in_a[p], in_b[p], q, out_c[q], out_d[q], 0};
+      std::copy(r, r + 8, &erec[8 * (size_t)p]);
+    }
+    while (b.w.size() % 16) b.w.push_back(0);
+    b.put(TH_EREC, erec);
+  }
   {
     std::vector<int32_t> lane_bus(N);
     std::iota(lane_bus.begin(), lane_bus.end(), 0);
@@ -138,7 +148,8 @@ int build(int N, int E, int Gn, const int32_t* src, const int32_t* dst, const in
 
 size_t blob_words(int N, int E, int Gn) {
   return TH_HDR_WORDS + 2 * (size_t)(N + 1) + 12 * (size_t)E + (size_t)N + (size_t)(N + 1) + (size_t)std::max(Gn, 1)
-         + 4 * (size_t)GNS_NPART * (GNS_MAXP + 1) + (size_t)(N + 1) + 5 * (size_t)E + (size_t)N;
+         + 4 * (size_t)GNS_NPART * (GNS_MAXP + 1) + (size_t)(N + 1) + 5 * (size_t)E + (size_t)N
+         + 8 * (size_t)E + 16;                                                   // line records and their 64-byte alignment
 }
 
 }  // namespace
