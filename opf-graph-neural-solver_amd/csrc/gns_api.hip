@@ -431,6 +431,7 @@ extern "C" int gns_backward(const gns_config* cfg, const void* topo_dev, const f
   rc = gns_launch_backward(d, h, cfg->multiple_phi, tuning().dw_mfma, tuning().bwd_variant, A, blocks, st);
   prof_mark(1, false, st);
   if (rc != GNS_OK) return rc;
-  return gns_launch_reduce(A.slab, (float*)(bw + B.off_part), (float*)(bw + B.off_tmp), params, grad_params, nslab, B.slab_floats,
-                           fam, K, d, h, st);
+  // the kernel has summed each workgroup's eight slabs into its first one: one slab per workgroup is left to reduce
+  return gns_launch_reduce(A.slab, (float*)(bw + B.off_part), (float*)(bw + B.off_tmp), params, grad_params, blocks, B.slab_floats,
+                           fam, K, d, h, st, (long long)GNS_BWD_WAVES * B.slab_floats);
 }

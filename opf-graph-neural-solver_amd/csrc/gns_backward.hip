@@ -260,9 +260,11 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
         const float dbar2 = Tb * vt * vt * o0.x * cD2 - Cb;
         dtht += Cb; dths -= Cb;
 #ifdef GNS_ABLATE_PHYS_STORE      // diagnostic: the six results are computed but not stored
-        asm volatile("" :: "v"(dvs), "v"(dvt), "v"(dths), "v"(dtht), "v"(dbar), "v"(dbar2));
+        asm volatile("" :: "v"(dvs), "v"(dvt), "v"(dths), "v"(dbar), "v"(dbar2));
 #else
-        *slot_ptr(0, p) = dvs; *slot_ptr(1, p) = dvt; *slot_ptr(2, p) = dths; *slot_ptr(3, p) = dtht;
+        // dtht == -dths bit for bit (Bb - Ab + Cb against Ab - Bb - Cb): plane 3 is not written, the gather negates plane 2
+        (void)dtht;
+        *slot_ptr(0, p) = dvs; *slot_ptr(1, p) = dvt; *slot_ptr(2, p) = dths;
         *slot_ptr(4, p) = dbar; *slot_ptr(5, p) = dbar2;
 #endif
       };
@@ -300,7 +302,7 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
         {
           float ai[4], bi[4], ao[4], bo[4], ci[8];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { const int pp = min(p0 + j, max(p1 - 1, p0)); ai[j] = *slot_ptr(1, min(pp, E - 1)); bi[j] = *slot_ptr(3, min(pp, E - 1)); }
+          for (int j = 0; j < 4; ++j) { const int pp = min(p0 + j, max(p1 - 1, p0)); ai[j] = *slot_ptr(1, min(pp, E - 1)); bi[j] = -*slot_ptr(2, min(pp, E - 1)); }
 #pragma unroll
           for (int j = 0; j < 4; ++j) { const int p = q2p[min(min(q0 + j, max(q1 - 1, q0)), E - 1)]; ao[j] = *slot_ptr(0, p); bo[j] = *slot_ptr(2, p); }
 #pragma unroll
@@ -319,7 +321,7 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
         for (int p = p0 + 4; p < p1; p += 4) {
           float a[4], b[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { const int pp = min(p + j, p1 - 1); a[j] = *slot_ptr(1, pp); b[j] = *slot_ptr(3, pp); }
+          for (int j = 0; j < 4; ++j) { const int pp = min(p + j, p1 - 1); a[j] = *slot_ptr(1, pp); b[j] = -*slot_ptr(2, pp); }
 #pragma unroll
           for (int j = 0; j < 4; ++j) if (p + j < p1) { vbar += a[j]; thbar += b[j]; }
         }
@@ -870,6 +872,21 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
     team_barrier(team);
   }
   if (team_failed && lane == 0) slab[0] = __builtin_nanf("");          // a team barrier gave up: the gradients must not look valid
+  // The eight per-wave slabs of this workgroup are summed here, in wave order, into the first one (they are still in this
+  // CU's L1 / the XCD's L2): the reduction kernels then read one slab per workgroup instead of eight (121 MB -> 15 MB).
+  __syncthreads();
+  {
+    float* base = A.slab + (long long)blockIdx.x * W * A.slab_floats;
+    for (long long i = 4LL * threadIdx.x; i < A.slab_floats; i += 4LL * GNS_BWD_THREADS) {
+      f4 acc = *reinterpret_cast<const f4*>(base + i);
+#pragma unroll
+      for (int w = 1; w < W; ++w) {
+        const f4 t = *reinterpret_cast<const f4*>(base + w * A.slab_floats + i);
+        acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+      }
+      *reinterpret_cast<f4*>(base + i) = acc;
+    }
+  }
 #ifdef GNS_STAMPS
   if (lane == 0) for (int i = 0; i < 10; ++i) A.slots[((long long)blockIdx.x * W + wave) * 10 + i] = (float)tph[i];   // diagnostic build only: slots are dead by now
   if (lane == 0) for (int i = 0; i < 12; ++i) A.slots[(long long)gridDim.x * W * 10 + ((long long)blockIdx.x * W + wave) * 12 + i] = (float)tsw[i];
@@ -877,13 +894,13 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
 }
 
 // ---- slab reduction: grad[i] += sum over slabs, two fixed-order stages (bitwise reproducible) ----------
-__global__ void gns_reduce_stage1(const float* __restrict__ slab, float* __restrict__ part, long long nslab, long long sf) {
+__global__ void gns_reduce_stage1(const float* __restrict__ slab, float* __restrict__ part, long long nslab, long long sf, long long stride) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= sf) return;
   const long long j = blockIdx.y, s0 = nslab * j / GNS_RED_PARTS, s1 = nslab * (j + 1) / GNS_RED_PARTS;
   float acc = 0.f;
 #pragma unroll 8
-  for (long long s = s0; s < s1; ++s) acc += slab[s * sf + i];
+  for (long long s = s0; s < s1; ++s) acc += slab[s * stride + i];
   part[j * sf + i] = acc;
 }
 __global__ void gns_reduce_stage2(const float* __restrict__ part, float* __restrict__ out, long long sf, long long n) {
@@ -963,8 +980,9 @@ int gns_launch_backward(int d, int h, int multi, int mfma, int variant, const Gn
 }
 
 int gns_launch_reduce(const float* slab, float* part, float* tmp, const float* flat, float* grad, long long nslab, long long sf,
-                      const GnsFamilies& fam, int K, int D, int H, hipStream_t st) {
-  hipLaunchKernelGGL(gns_reduce_stage1, dim3((unsigned)((sf + 255) / 256), GNS_RED_PARTS), dim3(256), 0, st, slab, part, nslab, sf);
+                      const GnsFamilies& fam, int K, int D, int H, hipStream_t st, long long stride) {
+  if (stride <= 0) stride = sf;
+  hipLaunchKernelGGL(gns_reduce_stage1, dim3((unsigned)((sf + 255) / 256), GNS_RED_PARTS), dim3(256), 0, st, slab, part, nslab, sf, stride);
   hipLaunchKernelGGL(gns_reduce_stage2, dim3((unsigned)((fam.g_total + 255) / 256)), dim3(256), 0, st, part, tmp, sf, (long long)fam.g_total);
   hipLaunchKernelGGL(gns_unfold_kernel, dim3(fam.nfam * K), dim3(256), 0, st, tmp, flat, grad, fam, K, D, H);
   return hipGetLastError() == hipSuccess ? GNS_OK : GNS_ELAUNCH;
