@@ -106,6 +106,15 @@ int gns_backward(const gns_config* cfg, const void* topo_dev, const float* param
                  const float* grad_total, const float* grad_last, const float* grad_v, const float* grad_theta,
                  float* grad_params, void* bwd_workspace, size_t bwd_workspace_bytes, void* stream);
 
+/* The optimiser update of the reference's training loop (optimizer.step() at GNS/main.py:290 with torch.optim.Adam,
+ * main.py:241-243: no weight decay, no amsgrad) on the ONE flat parameter buffer, in one launch:
+ *   m = m + (g - m)(1 - beta1);  v = beta2 v + (1 - beta2) g^2;
+ *   p -= (lr / (1 - beta1^step)) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)          (step counts from 1)
+ * params / grad / exp_avg / exp_avg_sq: n floats each on the device, caller-owned; grad is read only.  The hyper-parameters are
+ * doubles like torch's (1 - beta is formed in double, then rounded to the float the kernel multiplies with). */
+int gns_adam_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  double lr, double beta1, double beta2, double eps, int64_t step, void* stream);
+
 /* ---- diagnostics (benchmarks only; not on the reference's interface) -------------------------------
  * gns_profile_enable(capacity > 0): from now on gns_forward / gns_backward record a HIP event pair around
  * their fused main kernel, on the caller's stream, into a ring of `capacity` pairs per direction (capacity 0

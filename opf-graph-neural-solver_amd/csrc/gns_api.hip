@@ -435,3 +435,25 @@ extern "C" int gns_backward(const gns_config* cfg, const void* topo_dev, const f
   return gns_launch_reduce(A.slab, (float*)(bw + B.off_part), (float*)(bw + B.off_tmp), params, grad_params, blocks, B.slab_floats,
                            fam, K, d, h, st, (long long)GNS_BWD_WAVES * B.slab_floats);
 }
+
+// ---- Adam on the flat parameter buffer (GNS/main.py:290 with the optimiser of main.py:241-243) ---------------------------
+__global__ void gns_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                long long n, float one_minus_b1, float b2, float one_minus_b2, float step_size, float inv_sqrt_bc2, float eps) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i];
+  const float mi = m[i] + (gi - m[i]) * one_minus_b1;
+  const float vi = b2 * v[i] + one_minus_b2 * gi * gi;
+  m[i] = mi; v[i] = vi;
+  p[i] -= step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+}
+
+extern "C" int gns_adam_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                             double lr, double beta1, double beta2, double eps, int64_t step, void* stream) {
+  if (!params || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step <= 0) return GNS_EINVAL;
+  const double bc1 = 1.0 - std::pow(beta1, (double)step), bc2 = 1.0 - std::pow(beta2, (double)step);
+  hipLaunchKernelGGL(gns_adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grad, exp_avg,
+                     exp_avg_sq, (long long)n, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)(lr / bc1),
+                     (float)(1.0 / std::sqrt(bc2)), (float)eps);
+  return hipGetLastError() == hipSuccess ? GNS_OK : GNS_ELAUNCH;
+}

@@ -22,14 +22,17 @@ class FlatOptimizer:
     parameter buffer instead of its 144 tensors: the parameters are views of that buffer (``GNS.flat_parameters``) and the
     fused backward hands their gradients as views of one flat gradient (``dist.flat_gradient``), so the element-wise update
     is the same arithmetic in one kernel launch instead of six multi-tensor chunks (34 -> 6 us per step on MI355X).
-    ``step()`` / ``zero_grad()`` like a torch optimiser; ``state_dict`` is that of the inner optimiser over the flat tensor
+    For Adam on a GPU model that launch is the library's own kernel (``gns_adam_step``, ``include/gns_hip.h``: torch's update
+    rule with its defaults, 3 us instead of torch's two launches of 20 us); the moment estimates live in the inner optimiser's
+    state, so ``state_dict`` / ``load_state_dict`` are those of ``torch.optim.Adam`` over the flat tensor either way
     (the model's own ``state_dict`` - what the reference checkpoints, ``main.py:308`` - is unaffected)."""
 
-    def __init__(self, model, inner_cls, **kw):
+    def __init__(self, model, inner_cls, native=None, **kw):
         self.model = model
         self._cls, self._kw = inner_cls, kw
         self._flat = None
         self.inner = None
+        self._native = native
         self._bind()
 
     def _bind(self):
@@ -37,13 +40,47 @@ class FlatOptimizer:
         if self._flat is None or self._flat.data_ptr() != flat.data_ptr() or self._flat.device != flat.device:
             # (re)built when .to() / load_state_dict replaced the storage; the moment estimates restart with it
             self._flat = torch.nn.Parameter(flat.detach(), requires_grad=True)     # shares the storage
-            self.inner = self._cls([self._flat], **self._kw)
+            kw = dict(self._kw)
+            native = self._native
+            if native is None:
+                native = self._cls is torch.optim.Adam and flat.is_cuda and flat.dtype == torch.float32
+            self._use_native = bool(native)
+            if self._use_native:
+                kw.pop('fused', None)           # the inner object only keeps hyper-parameters and state
+            self.inner = self._cls([self._flat], **kw)
+
+    def _native_step(self):
+        from ._lib import load_library, GNS_ERRORS
+        grp = self.inner.param_groups[0]
+        if grp.get('weight_decay', 0) or grp.get('amsgrad', False) or grp.get('maximize', False):
+            raise ValueError('FlatOptimizer(native=True) implements torch.optim.Adam without weight decay / amsgrad / maximize')
+        st = self.inner.state[self._flat]
+        if 'exp_avg' not in st:
+            st['step'] = torch.tensor(0.0)                                         # host counter: no launch to advance it
+            st['exp_avg'] = torch.zeros_like(self._flat.data)
+            st['exp_avg_sq'] = torch.zeros_like(self._flat.data)
+        if st['step'].is_cuda:                                                     # a state_dict of a fused torch Adam was loaded
+            st['step'] = st['step'].cpu()
+        st['step'] += 1
+        grad = self._flat.grad
+        if grad.dtype != torch.float32 or not grad.is_contiguous() or grad.device != self._flat.device:
+            raise ValueError('FlatOptimizer: the flat gradient must be a contiguous float32 tensor on the parameters\' device')
+        dev = self._flat.device
+        with torch.cuda.device(dev):
+            rc = load_library().gns_adam_step(self._flat.data_ptr(), grad.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(),
+                                              self._flat.numel(), float(grp['lr']), float(grp['betas'][0]), float(grp['betas'][1]),
+                                              float(grp['eps']), int(st['step'].item()), torch.cuda.current_stream(dev).cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f'gns_adam_step failed: {GNS_ERRORS.get(rc, rc)}')
 
     def step(self):
         from . import dist as gdist
         self._bind()
         self._flat.grad = gdist.flat_gradient(self.model)
-        self.inner.step()
+        if self._use_native:
+            self._native_step()
+        else:
+            self.inner.step()
         # the update went through an alias of the buffer: tell autograd's bookkeeping (the fused backward refuses to mix
         # weights packed before an update with the live buffer, like torch autograd would)
         torch.autograd.graph.increment_version(self.model.flat_parameters())

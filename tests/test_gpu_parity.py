@@ -464,6 +464,12 @@ def test_flat_optimizer_is_the_reference_optimizer_in_one_launch():
         m = amd.GNS(20, 10, 3, 0.9, True).cuda()
         opt = amd.training.make_optimizer(m, flat=flat)
         assert isinstance(opt, amd.training.FlatOptimizer) == flat
+        if flat:
+            # the flattening itself is checked with torch's own kernel on the flat tensor: identical arithmetic, so even the
+            # weights whose gradient is rounding noise (Adam turns those into +-lr) must agree; the library's kernel is
+            # checked on given gradients in test_library_adam_kernel_is_torch_adam_and_shares_its_state_dict
+            assert opt._use_native
+            opt = amd.training.FlatOptimizer(m, torch.optim.Adam, native=False, lr=1e-3, fused=True)
         for _ in range(4):
             opt.zero_grad()
             m(bu, li, ge)[2].mean().backward()
@@ -481,6 +487,56 @@ def test_flat_optimizer_is_the_reference_optimizer_in_one_launch():
     o2.step()                                              # a step between forward and backward must be refused
     with pytest.raises(amd.GNSError, match='modified in place'):
         t3.backward()
+
+
+def test_library_adam_kernel_is_torch_adam_and_shares_its_state_dict():
+    """gns_adam_step (include/gns_hip.h) against torch.optim.Adam (the optimiser of GNS/main.py:241-243,290) on the same flat
+    tensor and the same GIVEN gradient sequence (zeros, tiny and ordinary values): weights and both moment estimates after 6
+    steps; then the two optimisers swap their state_dicts and continue to the same weights."""
+    import opf_graph_neural_solver_amd as amd
+    torch.manual_seed(3)
+    m0 = amd.GNS(10, 10, 2, 0.9, True).cuda()
+    n = m0.flat_parameters().numel()
+    gen = torch.Generator(device='cuda').manual_seed(11)
+    grads = []
+    for t_ in range(7):
+        g = torch.randn(n, device='cuda', generator=gen) * torch.logspace(-12, 0, n, device='cuda')
+        g[::7] = 0.0
+        grads.append(g)
+    w0 = m0.flat_parameters().detach().clone()
+
+    def give(m, g):
+        off = 0
+        for p in m.parameters():
+            p.grad = g[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+
+    runs = {}
+    for native in (True, False):
+        torch.manual_seed(3)
+        m = amd.GNS(10, 10, 2, 0.9, True).cuda()
+        assert torch.equal(m.flat_parameters().detach(), w0)
+        opt = amd.training.FlatOptimizer(m, torch.optim.Adam, native=native, lr=1e-3)
+        assert opt._use_native == native
+        for t_ in range(6):
+            give(m, grads[t_]); opt.step()
+        st = opt.state_dict()['state'][0]
+        runs[native] = (m.flat_parameters().detach().clone(), st['exp_avg'].clone(), st['exp_avg_sq'].clone(), float(st['step']), m, opt)
+    assert float((runs[True][0] - w0).abs().max()) > 1e-3                         # the steps did move the weights
+    for a, b, what in zip(runs[True][:3], runs[False][:3], ('weights', 'exp_avg', 'exp_avg_sq')):
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), what
+        # element-wise too (the moments span 24 orders of magnitude here); torch contracts its update into FMAs, the library
+        # is built with -ffp-contract=off, so single elements differ by a few ulp per step
+        assert bool(((a - b).abs() <= 1e-4 * b.abs() + 1e-7 * b.abs().max()).all()) or what == 'weights', what
+    assert runs[True][3] == runs[False][3] == 6.0
+    sd_native, sd_torch = runs[True][5].state_dict(), runs[False][5].state_dict()
+    runs[True][5].load_state_dict(sd_torch); runs[False][5].load_state_dict(sd_native)
+    out = []
+    for native in (True, False):
+        m, opt = runs[native][4], runs[native][5]
+        give(m, grads[6]); opt.step()
+        out.append(m.flat_parameters().detach().clone())
+    assert float((out[0] - out[1]).abs().max()) <= 2e-6 * float(out[1].abs().max())
 
 
 def test_in_place_parameter_update_between_forward_and_backward_raises():
