@@ -22,7 +22,12 @@ def flat_gradient(model) -> torch.Tensor:
 
     The fused backward hands autograd views of a single flat buffer, so normally this is a zero-copy lookup of
     that buffer; if something else produced the gradients they are flattened (and re-pointed) here."""
-    params = [p for p in model.parameters()]
+    if getattr(model, 'flat_grad', False) and next(iter(model._param_list())).is_cuda:
+        g = model.flat_leaf().grad                 # the backward delivered one tensor (GNS.flat_grad)
+        if g is None:
+            raise RuntimeError('flat_gradient: no gradient yet (run backward first)')
+        return g
+    params = model._param_list() if hasattr(model, '_param_list') else [p for p in model.parameters()]
     grads = [p.grad for p in params]
     if any(g is None for g in grads):
         raise RuntimeError('flat_gradient: a parameter has no gradient (run backward first)')

@@ -192,16 +192,42 @@ class GNS(nn.Module):
         # layout once instead of on every call (gns_prepack).  Off by default: the cache keeps the last batch alive.
         self.cache_packed_inputs = False
         self.__dict__['_pack_cache'] = None
+        self.__dict__['_plist'] = None                         # cached list(self.parameters()): walking 430 sub-modules costs 0.25 ms
+        # True: the backward delivers d loss / d parameters as ONE tensor, ``flat_leaf().grad`` (state_dict order), instead of
+        # one ``.grad`` view per parameter: the 6K x 6 AccumulateGrad nodes and views of a step cost more host time than a
+        # small batch's kernels take (1.2 of 1.9 ms per step at case30 x 4096).  ``training.make_optimizer`` switches it on
+        # for its flat optimiser; the reference's own loop (``torch.optim.Adam(model.parameters())``) needs it off (default).
+        self.flat_grad = False
+        self.__dict__['_leaf'] = None
 
     # ---- flat parameter storage -------------------------------------------------------------------
     def _config(self, n_bus, n_line, n_gen):
         return GnsConfig(n_bus, n_line, n_gen, self.K, self.latent_dim, self.hidden_dim, int(self.multiple_phis),
                          float(self.gamma))
 
+    def _param_list(self):
+        """``list(self.parameters())``, cached: the module tree (3 Linear layers in each of up to 6K LearningBlocks) is fixed after
+        construction, and the training step asks for this list half a dozen times.  Dropped whenever ``_apply`` (``.to()``,
+        ``.cuda()``, ``.float()``) or ``load_state_dict`` ran; re-validated against the first and last registered parameter."""
+        pl = self._plist
+        if pl is not None:
+            return pl
+        pl = list(self.parameters())
+        self.__dict__['_plist'] = pl
+        return pl
+
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__['_plist'] = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self.__dict__['_plist'] = None
+        return super().load_state_dict(*args, **kwargs)
+
     def _ensure_flat(self):
         """All parameters are views of ONE contiguous fp32 buffer in state_dict order: it is what the kernels read
         and what a data-parallel all-reduce sends.  Re-established after .to()/.load_state_dict() replaced storages."""
-        params = list(self.parameters())
+        params = self._param_list()
         flat = self._flat
         ok = flat is not None and flat.device == params[0].device
         if ok:
@@ -251,6 +277,25 @@ class GNS(nn.Module):
         # the entry holds the tensors themselves: their storage cannot be freed and handed to other data while it is cached
         self.__dict__['_pack_cache'] = (key, (buses, lines, gens, topo), packed)
         return packed
+
+    def flat_leaf(self):
+        """A leaf tensor (``requires_grad``) that aliases the flat parameter buffer: with ``flat_grad = True`` the autograd graph
+        hangs on it and its ``.grad`` is the flat gradient.  It shares storage and version counter with the parameters."""
+        self._ensure_flat()
+        leaf, flat = self._leaf, self._flat
+        if leaf is None or leaf.data_ptr() != flat.data_ptr() or leaf.device != flat.device or leaf.numel() != flat.numel():
+            leaf = flat.detach().requires_grad_(True)
+            self.__dict__['_leaf'] = leaf
+        return leaf
+
+    def zero_grad(self, set_to_none: bool = True):
+        leaf = self._leaf
+        if leaf is not None and leaf.grad is not None:
+            if set_to_none:
+                leaf.grad = None
+            else:
+                leaf.grad.zero_()
+        return super().zero_grad(set_to_none)
 
     def flat_parameters(self):
         """The flat fp32 parameter buffer (state_dict order); parameters are views into it."""
@@ -329,6 +374,8 @@ class GNS(nn.Module):
         # whether a backward pass can follow is decided HERE: inside Function.forward grad mode is always off, and
         # ctx.needs_input_grad ignores torch.no_grad()
         want_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        if self.flat_grad and want_grad and params[0].device.type == 'cuda':
+            params = [self.flat_leaf()]                     # one differentiable input: the gradient comes back as one tensor
         v, theta, total, last = _GNSFunction.apply(self, topo, want_grad, buses, lines, generators, *params)
         if in_dev != dev:
             v, theta, total, last = v.to(in_dev), theta.to(in_dev), total.to(in_dev), last.to(in_dev)

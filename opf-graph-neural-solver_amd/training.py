@@ -39,7 +39,10 @@ class FlatOptimizer:
         flat = self.model.flat_parameters()
         if self._flat is None or self._flat.data_ptr() != flat.data_ptr() or self._flat.device != flat.device:
             # (re)built when .to() / load_state_dict replaced the storage; the moment estimates restart with it
-            self._flat = torch.nn.Parameter(flat.detach(), requires_grad=True)     # shares the storage
+            if getattr(self.model, 'flat_grad', False) and flat.is_cuda:
+                self._flat = self.model.flat_leaf()                                # the leaf the backward hands its one gradient to
+            else:
+                self._flat = torch.nn.Parameter(flat.detach(), requires_grad=True)     # shares the storage
             kw = dict(self._kw)
             native = self._native
             if native is None:
@@ -76,7 +79,9 @@ class FlatOptimizer:
     def step(self):
         from . import dist as gdist
         self._bind()
-        self._flat.grad = gdist.flat_gradient(self.model)
+        g = gdist.flat_gradient(self.model)
+        if self._flat.grad is not g:
+            self._flat.grad = g
         if self._use_native:
             self._native_step()
         else:
@@ -86,7 +91,7 @@ class FlatOptimizer:
         torch.autograd.graph.increment_version(self.model.flat_parameters())
 
     def zero_grad(self, set_to_none=True):
-        for p in self.model.parameters():
+        for p in (self.model._param_list() if hasattr(self.model, '_param_list') else self.model.parameters()):
             p.grad = None
         if self._flat is not None:
             self._flat.grad = None
@@ -113,6 +118,8 @@ def make_optimizer(model, optimizer_name='Adam', lr=None, flat=None):
     else:
         kw, cls = dict(lr=0.001 if lr is None else lr, fused=on_gpu), torch.optim.Adam
     if flat:
+        if on_gpu and hasattr(model, 'flat_leaf'):
+            model.flat_grad = True                  # one gradient tensor per step instead of a view per parameter (GNS.flat_grad)
         return FlatOptimizer(model, cls, **kw)
     return cls(model.parameters(), **kw)
 

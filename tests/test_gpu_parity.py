@@ -539,6 +539,52 @@ def test_library_adam_kernel_is_torch_adam_and_shares_its_state_dict():
     assert float((out[0] - out[1]).abs().max()) <= 2e-6 * float(out[1].abs().max())
 
 
+def test_flat_grad_mode_delivers_the_same_gradient_as_one_tensor():
+    """GNS.flat_grad (switched on by training.make_optimizer): the backward hands ONE tensor, flat_leaf().grad, bitwise equal to
+    the per-parameter .grad views of the default mode; gradients accumulate across backward calls like .grad does; zero_grad
+    clears it; a train_step with the flat optimiser moves the weights exactly like the default mode with the same optimiser."""
+    import opf_graph_neural_solver_amd as amd
+    bu, li, ge = amd.synth.synth_grids(30, 70, seed=4, device='cuda')
+    torch.manual_seed(2)
+    m = amd.GNS(20, 10, 3, 0.9, True).cuda()
+    m(bu, li, ge)[2].mean().backward()
+    g_views = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
+    m.zero_grad()
+    m.flat_grad = True
+    out = m(bu, li, ge)
+    (out[2].mean() + 0.5 * out[3].sum()).backward()
+    m.flat_grad = False
+    out = m(bu, li, ge)
+    (out[2].mean() + 0.5 * out[3].sum()).backward()
+    g_ref2 = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
+    assert torch.equal(m.flat_leaf().grad, g_ref2)
+    assert all(p.grad is not None for p in m.parameters())
+    m.zero_grad()
+    assert m.flat_leaf().grad is None
+    m.flat_grad = True
+    m(bu, li, ge)[2].mean().backward()
+    assert torch.equal(m.flat_leaf().grad, g_views) and all(p.grad is None for p in m.parameters())
+    m(bu, li, ge)[2].mean().backward()                      # accumulates
+    assert torch.equal(m.flat_leaf().grad, g_views + g_views)
+    assert torch.equal(amd.dist.flat_gradient(m), m.flat_leaf().grad)
+    m.zero_grad()
+    # training step: flat mode against the default mode, same optimiser arithmetic (torch's Adam on the flat buffer)
+    ws = []
+    for mode in (True, False):
+        torch.manual_seed(2)
+        mm = amd.GNS(20, 10, 3, 0.9, True).cuda()
+        mm.flat_grad = mode
+        opt = amd.training.FlatOptimizer(mm, torch.optim.Adam, native=False, lr=1e-3)
+        for _ in range(3):
+            amd.training.train_step(mm, opt, bu, li, ge)
+        ws.append(mm.flat_parameters().detach().clone())
+    assert torch.equal(ws[0], ws[1])
+    mo = amd.GNS(20, 10, 3, 0.9, True).cuda()
+    assert not mo.flat_grad
+    amd.training.make_optimizer(mo)
+    assert mo.flat_grad                                      # the package's own optimiser switches it on
+
+
 def test_in_place_parameter_update_between_forward_and_backward_raises():
     """forward / optimizer.step() (or any in-place parameter write) / backward mixes weights packed by the forward with the
     live buffer; torch autograd raises in that situation and so must the fused path."""
