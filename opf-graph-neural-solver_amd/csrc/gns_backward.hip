@@ -223,7 +223,13 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
         L.Fb = row_ptr(A.adj, adj_row(t), lane)->z;                          // dp[t] += p_from   (main.py:94)
         L.Tb = row_ptr(A.adj, adj_row(s), lane)->z;                          // dp[s] += p_to     (main.py:95)
       };
-      auto edge_adjoint = [&](int p, const EdgeIn& L) {
+      struct EdgeOut { float dvs, dvt, dths, dbar, dbar2; };
+      auto edge_store = [&](int p, const EdgeOut& R) {
+        // dtht == -dths bit for bit (Bb - Ab + Cb against Ab - Bb - Cb): plane 3 is not written, the gather negates plane 2
+        *slot_ptr(0, p) = R.dvs; *slot_ptr(1, p) = R.dvt; *slot_ptr(2, p) = R.dths;
+        *slot_ptr(4, p) = R.dbar; *slot_ptr(5, p) = R.dbar2;
+      };
+      auto edge_adjoint = [&](int p, const EdgeIn& L, EdgeOut& R) {
         const f4 e1v = L.e1v, o0 = L.o0;
         const float Fb = L.Fb, Tb = L.Tb;
         const float vs = L.ss.x, ths = L.ss.y, vt = L.st.x, tht = L.st.y;
@@ -259,13 +265,12 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
         const float Cb = Tb * base2 * cC;
         const float dbar2 = Tb * vt * vt * o0.x * cD2 - Cb;
         dtht += Cb; dths -= Cb;
-#ifdef GNS_ABLATE_PHYS_STORE      // diagnostic: the six results are computed but not stored
-        asm volatile("" :: "v"(dvs), "v"(dvt), "v"(dths), "v"(dbar), "v"(dbar2));
-#else
-        // dtht == -dths bit for bit (Bb - Ab + Cb against Ab - Bb - Cb): plane 3 is not written, the gather negates plane 2
         (void)dtht;
-        *slot_ptr(0, p) = dvs; *slot_ptr(1, p) = dvt; *slot_ptr(2, p) = dths;
-        *slot_ptr(4, p) = dbar; *slot_ptr(5, p) = dbar2;
+#ifdef GNS_ABLATE_PHYS_STORE      // diagnostic: the results are computed but not stored
+        asm volatile("" :: "v"(dvs), "v"(dvt), "v"(dths), "v"(dbar), "v"(dbar2));
+        R = EdgeOut{0.f, 0.f, 0.f, 0.f, 0.f};
+#else
+        R = EdgeOut{dvs, dvt, dths, dbar, dbar2};
 #endif
       };
 #ifdef GNS_ABLATE_PHYS
@@ -274,10 +279,12 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
       for (int p = e0; p < e1; p += 2) {
 #endif
         EdgeIn L0, L1;
+        EdgeOut R0, R1;
         edge_load(p, L0);
         edge_load(min(p + 1, e1 - 1), L1);
-        edge_adjoint(p, L0);
-        if (p + 1 < e1) edge_adjoint(p + 1, L1);
+        edge_adjoint(p, L0, R0);
+        edge_store(p, R0);
+        if (p + 1 < e1) { edge_adjoint(p + 1, L1, R1); edge_store(p + 1, R1); }
       }
       STAMP(2)
       team_barrier(team);
