@@ -17,12 +17,10 @@
 
 #include "gns_dw.h"
 
-
-
 #ifndef GNS_BWD_PLANES
-#define GNS_BWD_PLANES 1
+#define GNS_BWD_PLANES 1          // 0 (diagnostic build): the line phase gathers its neighbour values from HBM / L2 rows
 #endif
-typedef int gns_i8v __attribute__((ext_vector_type(8)));
+typedef int gns_i8v __attribute__((ext_vector_type(8)));   // one line record of TH_EREC
 
 // ------------------------------------------------------------------------------------------------
 // V2 (three phi nets, matrix-pipe engine): the family sweep runs the layer-wise data path - each layer's weight gradient is
