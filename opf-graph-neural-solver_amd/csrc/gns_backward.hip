@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
             if (k < K - 1) {
               a = f4{a.x + xs[j].x, a.y + xs[j].y, xs[j].z, 0.f};           // main.py:182,186 identity paths
 #pragma unroll
-              for (int q = 0; q < 1 + RHB; ++q) *row_ptr(A.adj, ar + 1 + q, lane) = f4{0.f, 0.f, 0.f, 0.f};
+              for (int q = (VAR == 2 ? 1 : 0); q < 1 + RHB; ++q) *row_ptr(A.adj, ar + 1 + q, lane) = f4{0.f, 0.f, 0.f, 0.f};   // (VAR 2: the first sweep of a step starts the input-adjoint row itself)
             }
             a.z = a.z + cdp * s1[j].z;
             *row_ptr(A.adj, ar, lane) = a;
@@ -607,10 +607,14 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
         using L1 = WLink<true, true>;             // middle
         using L2 = WLink<true, false>;            // last
         SSTAMP(11)
+        const bool first_family = (l == 2) || (l == 0 && k == K - 1);
         for (int n = n0; n < n1; ++n) {
           const long long ar = adj_row(n), rr = state_row(k, n);
           const f4 a0 = *row_ptr(A.adj, ar, lane);
-          f4 xsum = *row_ptr(A.adj, ar + 1, lane);            // d/dv, d/dtheta, d/ddp of the L inputs so far
+          // d/dv, d/dtheta, d/ddp of the L inputs so far: the first sweep of a step (L_m, or L_theta at the last step where L_m
+          // has no gradient) starts from zero without reading the row, and Pb-0 does not have to clear it
+          f4 xsum = f4{0.f, 0.f, 0.f, 0.f};
+          if (!first_family) xsum = *row_ptr(A.adj, ar + 1, lane);
           const f4 s0 = *row_ptr(A.state, rr, lane);
           f2 xs[XL];                                          // [v theta | dp dq | m | sum_e h_e | deg, 1]
           f2 (&m)[D / 2] = reinterpret_cast<f2 (&)[D / 2]>(xs[2]);
