@@ -138,8 +138,12 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
       const float tb = (live && A.g_theta) ? A.g_theta[b * N + n] : 0.f;
       const long long ar = adj_row(n);
       *row_ptr(A.adj, ar, lane) = f4{vb, tb, 0.f, 0.f};
+      // (VAR 2: nothing else to clear - the first sweep of a step starts the input-adjoint row itself, and the latent adjoint is
+      //  known to be zero where it is first read, in the L_theta sweep of the last step)
+      if constexpr (VAR != 2) {
 #pragma unroll
-      for (int q = 0; q < RBA - 1; ++q) *row_ptr(A.adj, ar + 1 + q, lane) = f4{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < RBA - 1; ++q) *row_ptr(A.adj, ar + 1 + q, lane) = f4{0.f, 0.f, 0.f, 0.f};
+      }
     }
 
     for (int k = K - 1; k >= 0; --k) {
@@ -621,7 +625,12 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
           f2 (&S)[H / 2] = reinterpret_cast<f2 (&)[H / 2]>(xs[SOFF]);
           load_pairs<D>(A.state, rr + 1, lane, m);
           f2 macc[D / 2];                                     // d/dm_{k+1} (identity path main.py:188), keeps accumulating
-          load_pairs<D>(A.adj, ar + RM, lane, macc);
+          if (l == 0 && k == K - 1) {                         // nothing has touched it yet: zero, and never written before this sweep
+#pragma unroll
+            for (int i = 0; i < D / 2; ++i) macc[i] = f2{0.f, 0.f};
+          } else {
+            load_pairs<D>(A.adj, ar + RM, lane, macc);
+          }
 #ifdef GNS_ABLATE_HBM
           load_pairs<H>(A.msg, ((((long long)0 * A.G + g) * N + (n & 3)) * C::NPHI + fphi) * C::HQ, lane, S);
 #else
