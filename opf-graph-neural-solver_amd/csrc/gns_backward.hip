@@ -612,24 +612,31 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
         using L2 = WLink<true, false>;            // last
         SSTAMP(11)
         const bool first_family = (l == 2) || (l == 0 && k == K - 1);
+        // Step 0 reads m_0 = 0 and produces adjoints of (v, theta, dp, m)_0 that nothing reads (the inputs carry no gradient):
+        // the latent rows are not loaded, the input-adjoint row and the latent adjoint are neither read (only L_m needs the
+        // latter, as its upstream) nor written.  A third of the sweeps' rows at K = 4.
+        const bool step0 = k == 0;
         for (int n = n0; n < n1; ++n) {
           const long long ar = adj_row(n), rr = state_row(k, n);
           const f4 a0 = *row_ptr(A.adj, ar, lane);
           // d/dv, d/dtheta, d/ddp of the L inputs so far: the first sweep of a step (L_m, or L_theta at the last step where L_m
           // has no gradient) starts from zero without reading the row, and Pb-0 does not have to clear it
           f4 xsum = f4{0.f, 0.f, 0.f, 0.f};
-          if (!first_family) xsum = *row_ptr(A.adj, ar + 1, lane);
+          // (step 0: the value is dead - the load goes to the first bus's row, which stays in cache, instead of branching around it:
+          //  a branch splits the round of loads at the top of a bus into two memory round trips)
+          const long long ar_ld = step0 ? adj_row(n0) : ar;
+          if (!first_family) xsum = *row_ptr(A.adj, ar_ld + 1, lane);
           const f4 s0 = *row_ptr(A.state, rr, lane);
           f2 xs[XL];                                          // [v theta | dp dq | m | sum_e h_e | deg, 1]
           f2 (&m)[D / 2] = reinterpret_cast<f2 (&)[D / 2]>(xs[2]);
           f2 (&S)[H / 2] = reinterpret_cast<f2 (&)[H / 2]>(xs[SOFF]);
-          load_pairs<D>(A.state, rr + 1, lane, m);
+          load_pairs<D>(A.state, (step0 ? state_row(0, n0) : rr) + 1, lane, m);   // m_0 = 0 for every bus: step 0 reads one (cached) bus's zero rows
           f2 macc[D / 2];                                     // d/dm_{k+1} (identity path main.py:188), keeps accumulating
           if (l == 0 && k == K - 1) {                         // nothing has touched it yet: zero, and never written before this sweep
 #pragma unroll
             for (int i = 0; i < D / 2; ++i) macc[i] = f2{0.f, 0.f};
           } else {
-            load_pairs<D>(A.adj, ar + RM, lane, macc);
+            load_pairs<D>(A.adj, (l != 2 ? ar_ld : ar) + RM, lane, macc);   // (L_theta / L_v at step 0: write-only and dead)
           }
 #ifdef GNS_ABLATE_HBM
           load_pairs<H>(A.msg, ((((long long)0 * A.G + g) * N + (n & 3)) * C::NPHI + fphi) * C::HQ, lane, S);
@@ -749,8 +756,10 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
             });
           }
           SSTAMP(9)
-          *row_ptr(A.adj, ar + 1, lane) = xsum;
-          store_pairs<D>(A.adj, ar + RM, lane, macc);
+          if (!step0) {
+            *row_ptr(A.adj, ar + 1, lane) = xsum;
+            store_pairs<D>(A.adj, ar + RM, lane, macc);
+          }
           SSTAMP(10)
         }
         {   // flush the family's tiles into the wave's slab (folded blocks: W1[H][IN] b1 W2 b2 [W4 b4])

@@ -267,7 +267,12 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
       const long long rr = state_row(rs, n), wr = state_row(ws, n);
       const f4 s0 = *row_ptr(A.state, rr, lane);
       f2 m[D / 2];
-      load_pairs<D>(A.state, rr + 1, lane, m);
+      if (k == 0) {                                         // m_0 = 0 (main.py:141): known, not read back
+#pragma unroll
+        for (int i = 0; i < D / 2; ++i) m[i] = f2{0.f, 0.f};
+      } else {
+        load_pairs<D>(A.state, rr + 1, lane, m);
+      }
       const int p0 = in_ptr[n], p1 = in_ptr[n + 1];
       f2 S[NL][H / 2];                                      // sum over the lines ending at n of the hidden vector of phi'
 #pragma unroll
@@ -326,7 +331,7 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
           mlp_fwd<C::LF_IN, H, D>(PT + A.t_off[C::NPHI + 2] + koff * A.t_sz[C::NPHI + 2], x, a1, a2, upd_m);
 #pragma unroll
           for (int i = 0; i < D / 2; ++i) m_new[i] = m[i] + upd_m[i];        // main.py:188
-          store_pairs_nt<D>(A.state, wr + 1, lane, m_new);
+          if (k < K - 1) store_pairs_nt<D>(A.state, wr + 1, lane, m_new);   // nothing reads m_K (the reference's L_m.{K-1} has no gradient)
         }
       });
       if constexpr (grp == 0) { if (use_plane) plane[n * GNS_LANES + lane] = vth_new; }
