@@ -165,6 +165,9 @@ __global__ void gns_pack_inputs_kernel(const int* __restrict__ topo, const float
 
 // ------------------------------------------------------------------------------------------------
 // The fused forward kernel.
+#ifndef GNS_FWD_ROW_STORES
+#define GNS_FWD_ROW_STORES 0      // 1 (diagnostic): keep the dead partial stores of theta / v into the state row
+#endif
 // ------------------------------------------------------------------------------------------------
 template <int D, int H, bool MULTI>
 __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwdArgs A) {
@@ -323,9 +326,12 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
         if constexpr (l < 2) {
           f2 y[1];
           mlp_fwd<C::LF_IN, H, 2>(PT + A.t_off[C::NPHI + l] + koff * A.t_sz[C::NPHI + l], x, a1, a2, y);
+          // With the LDS plane inside one workgroup the physics phase takes (v, theta) from the plane and then writes the whole
+          // state row: the two 4-byte-per-lane stores into that row (every 64-byte sector of 1 KiB touched for 256 bytes) are dead
           float* r0 = reinterpret_cast<float*>(row_ptr(A.state, wr, lane));
-          if constexpr (l == 0) { vth_new.y = s0.y + y[0].x; r0[1] = vth_new.y; }                    // theta += L_theta        (main.py:182)
-          else { vth_new.x = is_gen[n] ? s0.x : s0.x + y[0].x; r0[0] = vth_new.x; }                  // v += L_v off generators (main.py:184-186)
+          const bool row_needed = !(use_plane && tsize == 1) || GNS_FWD_ROW_STORES;
+          if constexpr (l == 0) { vth_new.y = s0.y + y[0].x; if (row_needed) r0[1] = vth_new.y; }                    // theta += L_theta        (main.py:182)
+          else { vth_new.x = is_gen[n] ? s0.x : s0.x + y[0].x; if (row_needed) r0[0] = vth_new.x; }                  // v += L_v off generators (main.py:184-186)
         } else {
           f2 upd_m[D / 2], m_new[D / 2];
           mlp_fwd<C::LF_IN, H, D>(PT + A.t_off[C::NPHI + 2] + koff * A.t_sz[C::NPHI + 2], x, a1, a2, upd_m);
