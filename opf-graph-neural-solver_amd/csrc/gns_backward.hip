@@ -40,12 +40,10 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
   cip topo = (cip)A.topo;
   cfp PT = (cfp)A.pt;
   cfp PN = (cfp)A.pn;
-  const cip in_ptr = topo + topo[TH_IN_PTR], in_src = topo + topo[TH_IN_SRC], in_dst = topo + topo[TH_IN_DST],
-            in_a = topo + topo[TH_IN_A], in_b = topo + topo[TH_IN_B], out_ptr = topo + topo[TH_OUT_PTR],
-            out_c = topo + topo[TH_OUT_C], out_d = topo + topo[TH_OUT_D], is_gen = topo + topo[TH_IS_GEN],
-            p2q = topo + topo[TH_P2Q], q2p = topo + topo[TH_Q2P], incd_ptr = topo + topo[TH_INCD_PTR],
+  const cip in_ptr = topo + topo[TH_IN_PTR], out_ptr = topo + topo[TH_OUT_PTR], is_gen = topo + topo[TH_IS_GEN],
+            q2p = topo + topo[TH_Q2P], incd_ptr = topo + topo[TH_INCD_PTR],
             incd = topo + topo[TH_INCD], part = topo + topo[TH_PART] + A.part_idx * (GNS_MAXP + 1),
-            epart = topo + topo[TH_EPART] + A.part_idx * (GNS_MAXP + 1);
+            epart = topo + topo[TH_EPART] + A.part_idx * (GNS_MAXP + 1);     // (the per-line indices come as one record: TH_EREC)
   // team of A.team workgroups per 64-grid group (gns_device.h, "teams"); blocks 8 apart share an XCD when the count allows it
   const int tsize = A.team, nteams = gridDim.x / tsize;
   int team_id = blockIdx.x, member = 0;
@@ -159,6 +157,7 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
       float lb = 0.f;
       for (int nb = n0; nb < n1; nb += 4) {                                  // four buses per round: 16 independent row loads in flight
         f4 s1[4], a0[4], xs[4], b1[4];
+        float gs[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int n = min(nb + j, n1 - 1);
@@ -167,6 +166,7 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
           a0[j] = *row_ptr(A.adj, ar, lane);
           xs[j] = *row_ptr(A.adj, ar + 1, lane);
           b1[j] = *row_ptr(IN, in_base + 3LL * n + 1, lane);                // Pmin,Pset,Pmax per bus
+          gs[j] = row_ptr(IN, in_base + 3LL * n, lane)->z;                  // Gs
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -180,6 +180,7 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
               for (int q = (VAR == 2 ? 1 : 0); q < 1 + RHB; ++q) *row_ptr(A.adj, ar + 1 + q, lane) = f4{0.f, 0.f, 0.f, 0.f};   // (VAR 2: the first sweep of a step starts the input-adjoint row itself)
             }
             a.z = a.z + cdp * s1[j].z;
+            a.w = 2.f * gs[j] * s1[j].x;        // 2 Gs v for pass G, which then needs neither the state row nor the input row of the bus
             *row_ptr(A.adj, ar, lane) = a;
             if (use_plane) { pl_v[n * GNS_LANES + lane] = s1[j].x; pl_th[n * GNS_LANES + lane] = s1[j].y; pl_dp[n * GNS_LANES + lane] = a.z; }
             lb += a.z * (low2 ? 2.f * (b1[j].y - b1[j].x) : 2.f * (b1[j].z - b1[j].y));    // d Pg_new / d lambda  (main.py:53-57)
@@ -300,8 +301,6 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
 #endif
         const long long ar = adj_row(n);
         const f4 a0 = *row_ptr(A.adj, ar, lane);
-        const f4 s1 = *row_ptr(A.state, state_row(k + 1, n), lane);         // issued with the list loads below, used after them
-        const float Gs = row_ptr(IN, in_base + 3LL * n, lane)->z;
         float vbar = a0.x, thbar = a0.y;
         const float dpb = a0.z;
         // The three lists (lines ending here, lines leaving here, angle-difference incidences) are read with clamped
@@ -352,7 +351,7 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
 #pragma unroll
           for (int j = 0; j < 8; ++j) if (i + j < i1) thbar += a[j];
         }
-        vbar += (pgbar - dpb) * (2.f * Gs * s1.x);     // -Gs v^2 in dp (main.py:82) and +Gs v^2 in p_global (main.py:45)
+        vbar += (pgbar - dpb) * a0.w;                  // a0.w = 2 Gs v (Pb-0): -Gs v^2 in dp (main.py:82) and +Gs v^2 in p_global (main.py:45)
         *row_ptr(A.adj, ar, lane) = f4{vbar, thbar, dpb, 0.f};
       }
 
