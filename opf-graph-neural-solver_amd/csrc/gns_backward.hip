@@ -157,7 +157,6 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
       float lb = 0.f;
       for (int nb = n0; nb < n1; nb += 4) {                                  // four buses per round: 16 independent row loads in flight
         f4 s1[4], a0[4], xs[4], b1[4];
-        float gs[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int n = min(nb + j, n1 - 1);
@@ -165,8 +164,7 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
           s1[j] = *row_ptr(A.state, state_row(k + 1, n), lane);
           a0[j] = *row_ptr(A.adj, ar, lane);
           xs[j] = *row_ptr(A.adj, ar + 1, lane);
-          b1[j] = *row_ptr(IN, in_base + 3LL * n + 1, lane);                // Pmin,Pset,Pmax per bus
-          gs[j] = row_ptr(IN, in_base + 3LL * n, lane)->z;                  // Gs
+          b1[j] = *row_ptr(IN, in_base + 3LL * n + 1, lane);                // Pmin,Pset,Pmax,Gs per bus
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -180,7 +178,7 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
               for (int q = (VAR == 2 ? 1 : 0); q < 1 + RHB; ++q) *row_ptr(A.adj, ar + 1 + q, lane) = f4{0.f, 0.f, 0.f, 0.f};   // (VAR 2: the first sweep of a step starts the input-adjoint row itself)
             }
             a.z = a.z + cdp * s1[j].z;
-            a.w = 2.f * gs[j] * s1[j].x;        // 2 Gs v for pass G, which then needs neither the state row nor the input row of the bus
+            a.w = 2.f * b1[j].w * s1[j].x;        // 2 Gs v for pass G, which then needs neither the state row nor the input row of the bus
             *row_ptr(A.adj, ar, lane) = a;
             if (use_plane) { pl_v[n * GNS_LANES + lane] = s1[j].x; pl_th[n * GNS_LANES + lane] = s1[j].y; pl_dp[n * GNS_LANES + lane] = a.z; }
             lb += a.z * (low2 ? 2.f * (b1[j].y - b1[j].x) : 2.f * (b1[j].z - b1[j].y));    // d Pg_new / d lambda  (main.py:53-57)

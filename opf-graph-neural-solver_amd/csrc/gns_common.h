@@ -56,7 +56,7 @@ enum {
 };
 
 // ---- packed per-grid inputs: float4 rows, [group][row][lane] ---------------------------------------
-// bus n    : rows 3n..3n+2      (Pd,Qd,Gs,Bs) (Pmin,Pset,Pmax,v0) (dp0,dq0,0,0)
+// bus n    : rows 3n..3n+2      (Pd,Qd,Gs,Bs) (Pmin,Pset,Pmax,Gs) (dp0,dq0,v0,0)
 // in-edge p: rows 3N+3p..+2     (r,x,b,tau) (shift, y_s,tau_s,sh_s) (b_s,0,0,0)      s = src[e] used as LINE number
 // out-edge q: row 3N+3E+q       (y_t,tau_t,sh_t,b_t)                                 t = dst[e] used as LINE number
 // grid     : row 3N+4E          (sumPd, sumPset, sumPmin, sumPmax)

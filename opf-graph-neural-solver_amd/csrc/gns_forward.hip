@@ -125,9 +125,9 @@ __global__ void gns_pack_inputs_kernel(const int* __restrict__ topo, const float
     }
     const float v0 = (vg == 0.f) ? 1.f : vg;                        // main.py:146-147
     put(3LL * n, bq);
-    put(3LL * n + 1, f4{pmin, pset, pmax, v0});
+    put(3LL * n + 1, f4{pmin, pset, pmax, bq.z});                   // + Gs: all the backward's Pb-0 needs of a bus, in one row
     put(3LL * n + 2, f4{__fsub_rn(__fsub_rn(pg, bq.x), __fmul_rn(bq.z, __fmul_rn(v0, v0))),          // main.py:150
-                        __fadd_rn(__fsub_rn(qg, bq.y), __fmul_rn(bq.w, __fmul_rn(v0, v0))), 0.f, 0.f});   // main.py:152
+                        __fadd_rn(__fsub_rn(qg, bq.y), __fmul_rn(bq.w, __fmul_rn(v0, v0))), v0, 0.f});   // main.py:152
   } else if (c < cb + ci) {                                         // ---- line p in dst order: rows 3N + 3p ..
     const int p = (c - cb) * W + wave;
     if (p >= E) return;
@@ -235,9 +235,9 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
 
   // ---- prologue (main.py:141-152): m = 0, theta = 0, v = vg or 1, delta_p/q from the set points
   for (int n = n0; n < n1; ++n) {
-    const f4 b1 = *row_ptr(IN, in_base + 3LL * n + 1, lane), b2 = *row_ptr(IN, in_base + 3LL * n + 2, lane);
+    const f4 b2 = *row_ptr(IN, in_base + 3LL * n + 2, lane);       // dp0, dq0, v0
     const long long r0 = state_row(0, n);
-    *row_ptr(A.state, r0, lane) = f4{b1.w, 0.f, b2.x, b2.y};
+    *row_ptr(A.state, r0, lane) = f4{b2.z, 0.f, b2.x, b2.y};        // v0, 0, dp0, dq0
 #pragma unroll
     for (int q = 0; q < MQ; ++q) *row_ptr(A.state, r0 + 1 + q, lane) = f4{0.f, 0.f, 0.f, 0.f};
   }
@@ -452,7 +452,7 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int n = min(nb + j, q1w - 1);
-        b1[j] = *row_ptr(IN, in_base + 3LL * n + 1, lane);            // Pmin,Pset,Pmax,v0 summed per bus
+        b1[j] = *row_ptr(IN, in_base + 3LL * n + 1, lane);            // Pmin,Pset,Pmax summed per bus (, Gs)
         sn[j] = *row_ptr(A.state, state_row(ws, n), lane);
       }
 #pragma unroll
