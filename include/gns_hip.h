@@ -132,7 +132,8 @@ int gns_profile_read(int backward, float* ms_sum, int* launches);
  *   "train_mapping" training-mode forward + backward pair: same values
  *   "gw_pack"     grids per workgroup of the grid-per-workgroup mapping (0 = auto)
  *   "fwd_waves"   waves per workgroup of the lane-per-grid forward (1,2,4,8,16)
- *   "fwd_plane"   0: the lane-per-grid forward gathers neighbour (v, theta) from HBM instead of LDS
+ *   "fwd_plane"   LDS planes of the lane-per-grid forward: 0 none (neighbour (v, theta) gathered from HBM) | 1 the (v, theta) plane |
+ *                 2 (default) also (delta_p, delta_q) between the physics and the lambda phase of a step
  *   "bwd_variant" family sweep of the lane-per-grid backward: 1 wide half-wave records | 2 layer-wise sweep with sub-record
  *                 windows (default) | 3 = 2 with the contraction chains issued behind the weight streams
  *   "dw_mfma"     0: weight-gradient contraction on packed FMAs instead of the fp32 matrix pipe

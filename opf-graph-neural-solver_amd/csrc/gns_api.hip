@@ -12,7 +12,7 @@ struct GnsTuning {
   int fwd_mapping;   // GNS_FWD_MAPPING: 0 auto, 1 "lane" (lane = grid, state streamed through HBM), 2 "lds" (grid per workgroup, state on chip)
   int gw_pack;       // GNS_GW_PACK: grids per workgroup of the lds mapping (0 = auto)
   int fwd_waves;     // GNS_FWD_WAVES: waves per workgroup of the lane mapping
-  int fwd_plane;     // GNS_FWD_PLANE=0: lane mapping gathers neighbour (v, theta) from HBM instead of the LDS plane
+  int fwd_plane;     // GNS_FWD_PLANE: LDS planes of the lane-mapping forward: 0 none (neighbour (v, theta) from HBM), 1 the (v, theta) plane, 2 (default) also (delta_p, delta_q) between the physics and lambda phases
   int dw_mfma;       // GNS_DW_MFMA=0: packed-FMA weight-gradient engine instead of the matrix pipe
   int gw_ready;      // gns_gw_init_device() succeeded
   int train_mapping; // GNS_TRAIN_MAPPING: mapping of the training-mode forward + backward pair: 0 auto, 1 lane, 2 lds
@@ -21,7 +21,7 @@ struct GnsTuning {
   int ncu;           // compute units of the device (teams must be resident all at once)
 };
 GnsTuning make_tuning() {
-  GnsTuning t{0, 0, GNS_FWD_THREADS / 64, 1, 1, 0, 0, 2, 0, 0};
+  GnsTuning t{0, 0, GNS_FWD_THREADS / 64, 2, 1, 0, 0, 2, 0, 0};
   {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) t.ncu = n;
@@ -31,7 +31,7 @@ GnsTuning make_tuning() {
   if (const char* e = std::getenv("GNS_FWD_MAPPING")) t.fwd_mapping = !std::strcmp(e, "lane") ? 1 : (!std::strcmp(e, "lds") ? 2 : 0);
   if (const char* e = std::getenv("GNS_GW_PACK")) { const int p = std::atoi(e); if (p >= 1 && p <= 16) t.gw_pack = p; }
   if (const char* e = std::getenv("GNS_FWD_WAVES")) { const int w = std::atoi(e); if (gns_part_index(w) >= 0 && w * 64 <= GNS_FWD_MAX_THREADS) t.fwd_waves = w; }
-  if (const char* e = std::getenv("GNS_FWD_PLANE")) t.fwd_plane = e[0] == '0' ? 0 : 1;
+  if (const char* e = std::getenv("GNS_FWD_PLANE")) t.fwd_plane = e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2);
   if (const char* e = std::getenv("GNS_DW_MFMA")) t.dw_mfma = e[0] == '0' ? 0 : 1;
   if (const char* e = std::getenv("GNS_BWD_VARIANT")) { const int v = std::atoi(e); if (v >= 1 && v <= 3) t.bwd_variant = v; }
   if (const char* e = std::getenv("GNS_TRAIN_MAPPING")) t.train_mapping = !std::strcmp(e, "lane") ? 1 : (!std::strcmp(e, "lds") ? 2 : 0);
@@ -53,7 +53,7 @@ extern "C" int gns_set_option(const char* name, int value) {
   if (!std::strcmp(name, "train_mapping")) { if (value < 0 || value > 2) return GNS_EINVAL; t.train_mapping = value; return GNS_OK; }
   if (!std::strcmp(name, "gw_pack")) { if (value < 0 || value > 16) return GNS_EINVAL; t.gw_pack = value; return GNS_OK; }
   if (!std::strcmp(name, "fwd_waves")) { if (gns_part_index(value) < 0 || value * 64 > GNS_FWD_MAX_THREADS) return GNS_EINVAL; t.fwd_waves = value; return GNS_OK; }
-  if (!std::strcmp(name, "fwd_plane")) { t.fwd_plane = value ? 1 : 0; return GNS_OK; }
+  if (!std::strcmp(name, "fwd_plane")) { if (value < 0 || value > 2) return GNS_EINVAL; t.fwd_plane = value; return GNS_OK; }
   if (!std::strcmp(name, "dw_mfma")) { t.dw_mfma = value ? 1 : 0; return GNS_OK; }
   if (!std::strcmp(name, "team")) { if (value < 0 || value > GNS_MAX_TEAM) return GNS_EINVAL; t.team = value; return GNS_OK; }
   return GNS_EINVAL;
@@ -343,6 +343,7 @@ extern "C" int gns_forward(const gns_config* cfg, const void* topo_dev, const fl
   while (waves * A.team > GNS_MAXP) waves /= 2;
   A.part_idx = gns_part_index(waves * A.team);
   A.plane = (gns_fwd_plane_fits(N, A.team) && T.fwd_plane) ? 1 : 0;
+  if (A.plane && gns_fwd_plane2_fits(N, A.team) && T.fwd_plane == 2) A.plane = 2;
   if (A.team > 1 && hipMemsetAsync(A.team_ws, 0, (size_t)L.groups * GNS_TEAM_CTR_BYTES, st) != hipSuccess) return GNS_ELAUNCH;
   prof_mark(0, true, st);
   rc = gns_launch_forward(d, h, cfg->multiple_phi, A, waves * 64, st);

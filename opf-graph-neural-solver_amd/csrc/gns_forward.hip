@@ -208,8 +208,13 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
   extern __shared__ __attribute__((aligned(16))) unsigned char gns_dyn_lds[];
   f2* plane = reinterpret_cast<f2*>(gns_dyn_lds);
   const bool use_plane = A.plane != 0;
-  // per-wave partial sums [2 parities][GNS_MAXW][64][2] behind the plane; a team keeps them in HBM and the LDS goes to the plane
-  float* red = reinterpret_cast<float*>(gns_dyn_lds + (use_plane ? (size_t)N * GNS_LANES * sizeof(f2) : 0));
+  // A.plane == 2 (one workgroup per group and room for it): a second plane holds (delta_p before the generator term, delta_q)
+  // between the physics phase and the lambda phase of a step - the same wave owns a bus in both - so the state row is written
+  // once per step instead of written, re-read and written again
+  const bool use_plane2 = A.plane == 2;
+  f2* plane2 = plane + (size_t)N * GNS_LANES;
+  // per-wave partial sums [2 parities][GNS_MAXW][64][2] behind the planes; a team keeps them in HBM and the LDS goes to the plane
+  float* red = reinterpret_cast<float*>(gns_dyn_lds + (use_plane ? (size_t)N * GNS_LANES * sizeof(f2) : 0) * (use_plane2 ? 2 : 1));
   __shared__ int unit_ctr[2];                        // evaluation mode: work queue of the update phase, one counter per step parity
   __shared__ int team_failed;
   if (threadIdx.x < 2) unit_ctr[threadIdx.x] = 0;
@@ -429,7 +434,8 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
       const float dp_pre = ((0.f - b0.x) - b0.z * v2) + sum_pf + sum_pt;     // main.py:82,96 without the generator term
       const float qg_new = ((b0.y - b0.w * v2) - sum_qf) - sum_qt;           // main.py:64,76
       const float dq = ((qg_new - b0.y) + b0.w * v2) + sum_qf + sum_qt;      // main.py:83,103 (cancels to rounding noise)
-      *row_ptr(A.state, wr, lane) = f4{vn, thn, dp_pre, dq};
+      if (use_plane2) plane2[n * GNS_LANES + lane] = f2{dp_pre, dq};
+      else *row_ptr(A.state, wr, lane) = f4{vn, thn, dp_pre, dq};
     }
     FSTAMP(2)
     red_put(k & 1, joule, v2gs);
@@ -453,7 +459,12 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
       for (int j = 0; j < 4; ++j) {
         const int n = min(nb + j, q1w - 1);
         b1[j] = *row_ptr(IN, in_base + 3LL * n + 1, lane);            // Pmin,Pset,Pmax summed per bus (, Gs)
-        sn[j] = *row_ptr(A.state, state_row(ws, n), lane);
+        if (use_plane2) {
+          const f2 vt_ = plane[n * GNS_LANES + lane], pq_ = plane2[n * GNS_LANES + lane];
+          sn[j] = f4{vt_.x, vt_.y, pq_.x, pq_.y};
+        } else {
+          sn[j] = *row_ptr(A.state, state_row(ws, n), lane);
+        }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -498,7 +509,7 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
 
 template <int D, int H, bool MULTI>
 static int launch_forward_t(const GnsFwdArgs& A, int threads, hipStream_t st) {
-  const size_t dyn = (A.plane ? (size_t)A.N * GNS_LANES * sizeof(f2) : 0) + (A.team == 1 ? (size_t)GNS_FWD_RED_BYTES : 0);
+  const size_t dyn = (A.plane ? (size_t)A.N * GNS_LANES * sizeof(f2) : 0) * (A.plane == 2 ? 2 : 1) + (A.team == 1 ? (size_t)GNS_FWD_RED_BYTES : 0);
   static bool attr_ok[64] = {};                                      // > 64 KB of dynamic LDS needs the opt-in, once per kernel and device
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;

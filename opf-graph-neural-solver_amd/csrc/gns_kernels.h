@@ -16,6 +16,10 @@
 static inline int gns_fwd_plane_fits(int N, int team) {
   return (size_t)N * GNS_LANES * 8 + (team == 1 ? GNS_FWD_RED_BYTES : 0) <= (size_t)GNS_FWD_DYN_LDS_MAX;
 }
+// ... and the second plane (delta_p, delta_q between the physics and the lambda phase): one workgroup per group only
+static inline int gns_fwd_plane2_fits(int N, int team) {
+  return team == 1 && 2 * (size_t)N * GNS_LANES * 8 + GNS_FWD_RED_BYTES <= (size_t)GNS_FWD_DYN_LDS_MAX;
+}
 
 // (latent_dim, hidden_dim) pairs with compiled kernels
 #define GNS_FOR_EACH_DIMS(X) X(20, 10) X(10, 10)
@@ -45,7 +49,7 @@ struct GnsFwdArgs {
   float gw[GNS_MAX_K];    // gamma^(K-k) rounded to fp32 from a double, like the reference's python float
   long long Bt, G;
   int N, E, K, save, part_idx;
-  int plane;              // 1: the (v, theta) of the step being produced is mirrored in LDS ([N][64] float2, dynamic shared memory)
+  int plane;              // 1: the (v, theta) of the step being produced is mirrored in LDS ([N][64] float2, dynamic shared memory); 2: and (delta_p, delta_q) between the physics and lambda phases
   int team;               // workgroups per 64-grid group (1 = none); part_idx then names the partition for team * waves
   unsigned char* team_ws; // team > 1: [G] 64-byte counter lines (zero at launch) | [G][GNS_TEAM_RED_FLOATS] partial sums
 };
