@@ -165,6 +165,9 @@ __global__ void gns_pack_inputs_kernel(const int* __restrict__ topo, const float
 
 // ------------------------------------------------------------------------------------------------
 // The fused forward kernel.
+#ifndef GNS_FWD_SKIP_LAST_M
+#define GNS_FWD_SKIP_LAST_M 1      // 0 (diagnostic): run the dead m-family units of the last step like the reference does
+#endif
 #ifndef GNS_FWD_ROW_STORES
 #define GNS_FWD_ROW_STORES 0      // 1 (diagnostic): keep the dead partial stores of theta / v into the state row
 #endif
@@ -354,13 +357,19 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
     // a bit of the result.  Training mode keeps the fixed ranges: with the state / hidden-sum saves in flight the
     // drawn order measured 4 % slower.
     const bool draw = A.save == 0 && tsize == 1;
-    for (int u = u0;;) {
+    // The last step's m family is dead work: m_K feeds nothing (the reference's L_m.{K-1} / phi_m.{K-1} get no gradient for
+    // the same reason) and its hidden sums are only read by the backward sweep that is skipped.  The last step therefore
+    // runs the (theta, v) units only, dealt over ALL waves by the bus ranges (units [n0, n1) are group 0): 1/K of the m
+    // family's instructions and rows, and the waves that owned m units help with the rest.
+    const bool last_step = k == K - 1 && GNS_FWD_SKIP_LAST_M;
+    const int ub = last_step ? n0 : u0, ue = last_step ? n1 : u1, uall = last_step ? N : 2 * N;
+    for (int u = ub;;) {
       if (draw) {
         int t = 0;
         if (lane == 0) t = atomicAdd(&unit_ctr[k & 1], 1);
         u = __builtin_amdgcn_readfirstlane(t);
-        if (u >= 2 * N) break;
-      } else if (u >= u1) break;
+        if (u >= uall) break;
+      } else if (u >= ue) break;
       const int grp = u / N, n = u - grp * N;
       if (grp == 0) update_unit(std::integral_constant<int, 0>{}, n);
       else update_unit(std::integral_constant<int, 1>{}, n);
