@@ -222,11 +222,14 @@ __global__ void __launch_bounds__(MAXT, MINW) gns_gw_forward_kernel(GnsGwFwdArgs
             mlp_fwd<C::LF_IN, H, 2>(PT + A.t_off[NPHI + l] + koff * A.t_sz[NPHI + l], x, a1, a2, y);
             if constexpr (l == 0) th_new = sth + y[0].x;                        // main.py:182
             else v_new = isgen ? sv : sv + y[0].x;                             // main.py:184-186
-          } else {
+          } else if (k + 1 < K) {
             f2 y[D / 2];
             mlp_fwd<C::LF_IN, H, D>(PT + A.t_off[NPHI + 2] + koff * A.t_sz[NPHI + 2], x, a1, a2, y);
 #pragma unroll
             for (int i = 0; i < D / 2; ++i) m_new[i] = x[2 + i] + y[i];          // main.py:188
+          } else {                                                  // m_K feeds nothing: the last step's L_m is dead work
+#pragma unroll
+            for (int i = 0; i < D / 2; ++i) m_new[i] = x[2 + i];
           }
         });
         sv = v_new; sth = th_new;
@@ -238,6 +241,7 @@ __global__ void __launch_bounds__(MAXT, MINW) gns_gw_forward_kernel(GnsGwFwdArgs
         if (k + 1 < K) {                                              // bus share of phi' for the next step
           static_for<0, NPHI>([&](auto f_) {
             constexpr int f = decltype(f_)::value;
+            if (MULTI && f == 2 && k + 2 >= K) return;              // phi_m of the last step only feeds the dead L_m
             f2 uh[H / 2];
             phi_head<D, H>(PT + A.t_off[f] + (koff + 1) * A.t_sz[f], m, uh);
             if (is_bus) lds_write_row<H>(u_l + n * UW + f * H, uh);
@@ -276,6 +280,7 @@ __global__ void __launch_bounds__(MAXT, MINW) gns_gw_forward_kernel(GnsGwFwdArgs
         if (k + 1 < K) {
           static_for<0, NPHI>([&](auto f_) {
             constexpr int f = decltype(f_)::value;
+            if (MULTI && f == 2 && k + 2 >= K) return;              // (see BUS-1)
             f2 uh[H / 2], a1[H / 2], a2[H / 2];
             lds_read_row<H>(u_l + et * UW + f * H, uh);
             phi_tail<C::PHI_IN, H, D>(PT + A.t_off[f] + (koff + 1) * A.t_sz[f], uh, xt, a1, a2);
