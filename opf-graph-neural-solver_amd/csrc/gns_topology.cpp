@@ -112,7 +112,7 @@ int build(int N, int E, int Gn, const int32_t* src, const int32_t* dst, const in
     balanced_ranges(cost, wopts[i], &part[i * (GNS_MAXP + 1)]);
     balanced_ranges(ecost, wopts[i], &epart[i * (GNS_MAXP + 1)]);
     // Inside ONE workgroup (<= 16 waves) the m unit weighs 1.8 x its instruction estimate: it also streams 8 rows of saves
-    // (m_{k+1}, its hidden sums).  Measured on MI355X (tools/gpu_ucost_probe.py, case118 x 16384): factor 1.0 0.89 ms, 1.7 0.862,
+    // (m_{k+1}, its hidden sums).  Measured on MI355X through a temporary environment override of the factor (case118 x 16384): factor 1.0 0.89 ms, 1.7 0.862,
     // 1.8 0.851-0.856, 2.0 0.858, 2.5 0.896; d = 10 models -6 %.  Across a team of workgroups (32 waves on two CUs) the plain
     // estimate is the better split (case300 x 8192: 3.09 ms against 3.40 with the factor).
     std::vector<double> uc = ucost;
