@@ -16,12 +16,15 @@ struct GnsTuning {
   int dw_mfma;       // GNS_DW_MFMA=0: packed-FMA weight-gradient engine instead of the matrix pipe
   int gw_ready;      // gns_gw_init_device() succeeded
   int train_mapping; // GNS_TRAIN_MAPPING: mapping of the training-mode forward + backward pair: 0 auto, 1 lane, 2 lds
-  int bwd_variant;   // GNS_BWD_VARIANT: family sweep of the lane-per-grid backward: 1 wide half-wave records, 2 layer-wise + sub-record windows
+  int bwd_variant;   // GNS_BWD_VARIANT: lane-per-grid backward: 1 wide half-wave records, 2 layer-wise + sub-record windows, 3 = 2 + background chains (one persistent kernel each); 4 split: one kernel sequence per reverse step (gns_backward_split.hip)
   int team;          // GNS_TEAM: workgroups per 64-grid group of the lane mapping when the batch leaves CUs idle: 0 auto, 1 none, 2, 4
   int ncu;           // compute units of the device (teams must be resident all at once)
+  int split_ready;   // gns_bwds_init_device() succeeded
+  int bwds_mode;     // GNS_BWDS_MODE: sweep kernels per reverse step of the split backward: 0 one per family, 1 {L_m} {L_theta + L_v}, 2 all three families per bus in one kernel
+  int bwds_chunks;   // GNS_BWDS_CHUNKS: bus chunks per 64-grid group of the split backward's sweeps (0 = auto: 12, 24 or 32)
 };
 GnsTuning make_tuning() {
-  GnsTuning t{0, 0, GNS_FWD_THREADS / 64, 2, 1, 0, 0, 2, 0, 0};
+  GnsTuning t{0, 0, GNS_FWD_THREADS / 64, 2, 1, 0, 0, 4, 0, 0, 0, 1, 0};
   {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) t.ncu = n;
@@ -30,12 +33,15 @@ GnsTuning make_tuning() {
   if (const char* e = std::getenv("GNS_TEAM")) { const int v = std::atoi(e); if (v >= 0 && v <= GNS_MAX_TEAM) t.team = v; }
   if (const char* e = std::getenv("GNS_FWD_MAPPING")) t.fwd_mapping = !std::strcmp(e, "lane") ? 1 : (!std::strcmp(e, "lds") ? 2 : 0);
   if (const char* e = std::getenv("GNS_GW_PACK")) { const int p = std::atoi(e); if (p >= 1 && p <= 16) t.gw_pack = p; }
-  if (const char* e = std::getenv("GNS_FWD_WAVES")) { const int w = std::atoi(e); if (gns_part_index(w) >= 0 && w * 64 <= GNS_FWD_MAX_THREADS) t.fwd_waves = w; }
+  if (const char* e = std::getenv("GNS_FWD_WAVES")) { const int w = std::atoi(e); if (w > 0 && (w & (w - 1)) == 0 && w * 64 <= GNS_FWD_MAX_THREADS) t.fwd_waves = w; }
   if (const char* e = std::getenv("GNS_FWD_PLANE")) t.fwd_plane = e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2);
   if (const char* e = std::getenv("GNS_DW_MFMA")) t.dw_mfma = e[0] == '0' ? 0 : 1;
-  if (const char* e = std::getenv("GNS_BWD_VARIANT")) { const int v = std::atoi(e); if (v >= 1 && v <= 3) t.bwd_variant = v; }
+  if (const char* e = std::getenv("GNS_BWD_VARIANT")) { const int v = std::atoi(e); if (v >= 1 && v <= 4) t.bwd_variant = v; }
+  if (const char* e = std::getenv("GNS_BWDS_MODE")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) t.bwds_mode = v; }
+  if (const char* e = std::getenv("GNS_BWDS_CHUNKS")) { const int v = std::atoi(e); if (v == 0 || gns_part_index(v) >= 0) t.bwds_chunks = v; }
   if (const char* e = std::getenv("GNS_TRAIN_MAPPING")) t.train_mapping = !std::strcmp(e, "lane") ? 1 : (!std::strcmp(e, "lds") ? 2 : 0);
   t.gw_ready = (gns_gw_init_device() == GNS_OK && gns_gw_backward_init_device() == GNS_OK) ? 1 : 0;
+  t.split_ready = gns_bwds_init_device() == GNS_OK ? 1 : 0;
   return t;
 }
 GnsTuning& tuning() {
@@ -49,13 +55,15 @@ extern "C" int gns_set_option(const char* name, int value) {
   if (!name) return GNS_EINVAL;
   GnsTuning& t = tuning();
   if (!std::strcmp(name, "fwd_mapping")) { if (value < 0 || value > 2) return GNS_EINVAL; t.fwd_mapping = value; return GNS_OK; }
-  if (!std::strcmp(name, "bwd_variant")) { if (value < 1 || value > 3) return GNS_EINVAL; t.bwd_variant = value; return GNS_OK; }
+  if (!std::strcmp(name, "bwd_variant")) { if (value < 1 || value > 4) return GNS_EINVAL; t.bwd_variant = value; return GNS_OK; }
   if (!std::strcmp(name, "train_mapping")) { if (value < 0 || value > 2) return GNS_EINVAL; t.train_mapping = value; return GNS_OK; }
   if (!std::strcmp(name, "gw_pack")) { if (value < 0 || value > 16) return GNS_EINVAL; t.gw_pack = value; return GNS_OK; }
-  if (!std::strcmp(name, "fwd_waves")) { if (gns_part_index(value) < 0 || value * 64 > GNS_FWD_MAX_THREADS) return GNS_EINVAL; t.fwd_waves = value; return GNS_OK; }
+  if (!std::strcmp(name, "fwd_waves")) { if (value <= 0 || (value & (value - 1)) || value * 64 > GNS_FWD_MAX_THREADS) return GNS_EINVAL; t.fwd_waves = value; return GNS_OK; }
   if (!std::strcmp(name, "fwd_plane")) { if (value < 0 || value > 2) return GNS_EINVAL; t.fwd_plane = value; return GNS_OK; }
   if (!std::strcmp(name, "dw_mfma")) { t.dw_mfma = value ? 1 : 0; return GNS_OK; }
   if (!std::strcmp(name, "team")) { if (value < 0 || value > GNS_MAX_TEAM) return GNS_EINVAL; t.team = value; return GNS_OK; }
+  if (!std::strcmp(name, "bwds_mode")) { if (value < 0 || value > 2) return GNS_EINVAL; t.bwds_mode = value; return GNS_OK; }
+  if (!std::strcmp(name, "bwds_chunks")) { if (value != 0 && gns_part_index(value) < 0) return GNS_EINVAL; t.bwds_chunks = value; return GNS_OK; }
   return GNS_EINVAL;
 }
 extern "C" int gns_get_option(const char* name, int* value) {
@@ -69,6 +77,8 @@ extern "C" int gns_get_option(const char* name, int* value) {
   else if (!std::strcmp(name, "fwd_plane")) *value = t.fwd_plane;
   else if (!std::strcmp(name, "dw_mfma")) *value = t.dw_mfma;
   else if (!std::strcmp(name, "team")) *value = t.team;
+  else if (!std::strcmp(name, "bwds_chunks")) *value = t.bwds_chunks;
+  else if (!std::strcmp(name, "bwds_mode")) *value = t.bwds_mode;
   else return GNS_EINVAL;
   return GNS_OK;
 }
@@ -110,6 +120,12 @@ static int lane_team(int64_t Bt) {
   if (groups > GNS_TEAM_MAX_GROUPS) return 1;
   const int ncu = T.ncu < GNS_BWD_MAX_WG ? T.ncu : GNS_BWD_MAX_WG;
   return gns_team_size(groups, ncu, T.team);
+}
+
+// The split backward (bwd_variant 4) runs the three-phi models on the matrix-pipe engine; everything else keeps the persistent kernel.
+static bool use_split_backward(const gns_config* c) {
+  const GnsTuning& T = tuning();
+  return T.bwd_variant == 4 && T.split_ready && T.dw_mfma && gns_bwds_supported(c->latent_dim, c->hidden_dim, c->multiple_phi);
 }
 
 // Which mapping runs a training-mode forward and its backward.  Evaluated identically by gns_forward and gns_backward:
@@ -235,6 +251,11 @@ extern "C" int gns_workspace_bytes(const gns_config* cfg, int64_t Bt, int save_s
     GnsBwdLayout B;
     gns_bwd_layout(cfg->n_bus, cfg->n_line, cfg->latent_dim, cfg->hidden_dim, cfg->K, cfg->multiple_phi, Bt, lane_team(Bt), &B);
     *bwd_bytes = B.total;
+    if (tuning().split_ready && gns_bwds_supported(cfg->latent_dim, cfg->hidden_dim, cfg->multiple_phi)) {   // either variant may be asked for later
+      GnsBwdsLayout S;
+      gns_bwds_layout(cfg->n_bus, cfg->n_line, cfg->latent_dim, cfg->hidden_dim, cfg->K, cfg->multiple_phi, Bt, tuning().ncu, tuning().bwds_chunks, &S);
+      if (S.total > *bwd_bytes) *bwd_bytes = S.total;
+    }
   }
   return GNS_OK;
 }
@@ -395,6 +416,44 @@ extern "C" int gns_backward(const gns_config* cfg, const void* topo_dev, const f
   }
   GnsFwdLayout L;
   gns_fwd_layout(N, E, d, h, K, cfg->multiple_phi, Bt, 1, &L);
+  if (use_split_backward(cfg)) {
+    GnsBwdsLayout S;
+    gns_bwds_layout(N, E, d, h, K, cfg->multiple_phi, Bt, tuning().ncu, tuning().bwds_chunks, &S);
+    if (fwd_workspace_bytes < L.total || bwd_workspace_bytes < S.total) return GNS_ESIZE;
+    GnsFamilies fam; gns_families(d, h, K, cfg->multiple_phi, &fam);
+    hipStream_t st = (hipStream_t)stream;
+    const char* fw = (const char*)fwd_workspace;
+    char* bw = (char*)bwd_workspace;
+    GnsBwdsArgs A;
+    std::memset(&A, 0, sizeof(A));
+    A.topo = (const int*)topo_dev;
+    A.pt = (const float*)(fw + L.off_pt); A.pn = (const float*)(fw + L.off_pn);
+    A.in = packed_inputs ? (const float*)packed_inputs : (const float*)(fw + L.off_in);
+    A.state = (const float*)(fw + L.off_state); A.lam = (const float*)(fw + L.off_lam); A.msg = (const float*)(fw + L.off_msg);
+    A.g_total = grad_total; A.g_last = grad_last; A.g_v = grad_v; A.g_theta = grad_theta;
+    A.adj = (float*)(bw + S.off_adj); A.slots = (float*)(bw + S.off_slots); A.slab = (float*)(bw + S.off_slab);
+    for (int i = 0; i < fam.nfam; ++i) {
+      A.t_off[i] = fam.t_off[i]; A.t_sz[i] = fam.t_sz[i]; A.n_off[i] = fam.n_off[i]; A.n_sz[i] = fam.n_sz[i];
+      A.g_off[i] = fam.g_off[i]; A.g_sz[i] = fam.g_sz[i];
+    }
+    A.Bt = Bt; A.G = S.groups; A.slab_floats = S.slab_floats; A.N = N; A.E = E; A.K = K;
+    A.C = S.C; A.part_idx = gns_part_index(S.C); A.R = S.R;
+    A.RB = (int)(1 + S.mq); A.RBA = (int)S.adj_rows;
+    A.mode = tuning().bwds_mode;
+    const size_t lds = gns_bwds_phys_lds(N, &A.use_plane);
+    prof_mark(1, true, st);
+    for (int k = K - 1; k >= 0; --k) {
+      A.k = k;
+      A.gwk = (float)std::pow((double)cfg->gamma, (double)(K - k));
+      rc = gns_launch_bwds_phys(A, lds, st);
+      if (rc != GNS_OK) return rc;
+      rc = gns_launch_bwds_sweep(d, h, A, st);
+      if (rc != GNS_OK) return rc;
+    }
+    prof_mark(1, false, st);
+    return gns_launch_reduce(A.slab, (float*)(bw + S.off_part), (float*)(bw + S.off_tmp), params, grad_params, S.nslab, S.slab_floats,
+                             fam, K, d, h, st);
+  }
   GnsBwdLayout B;
   const int team = lane_team(Bt);
   gns_bwd_layout(N, E, d, h, K, cfg->multiple_phi, Bt, team, &B);

@@ -18,7 +18,7 @@
 
 #define GNS_LANES 64
 #define GNS_TOPO_MAGIC 0x474e5332  // "GNS2"
-#define GNS_NPART 6                // bus partitions are stored for 1,2,4,8,16,32 waves per 64-grid group
+#define GNS_NPART 8                // bus partitions are stored for 1,2,4,8,16,32 and 12,24 parts per 64-grid group
 #define GNS_MAXW 16                // waves of ONE workgroup (sizes the LDS reduction buffers)
 #define GNS_MAXP 32                // waves of one 64-grid group: up to GNS_MAX_TEAM workgroups share a group (gns_device.h, "teams")
 #define GNS_MAX_TEAM 4
@@ -63,7 +63,8 @@ enum {
 GNS_HD static inline int64_t gns_in_rows(int N, int E) { return 3LL * N + 4LL * E + 1; }
 
 static inline int gns_part_index(int waves) {
-  switch (waves) { case 1: return 0; case 2: return 1; case 4: return 2; case 8: return 3; case 16: return 4; case 32: return 5; default: return -1; }
+  switch (waves) { case 1: return 0; case 2: return 1; case 4: return 2; case 8: return 3; case 16: return 4; case 32: return 5;
+                   case 12: return 6; case 24: return 7; default: return -1; }   // 12, 24: bus chunks of the split backward (three one-wave workgroups per SIMD)
 }
 
 // "Teams": when a batch has fewer 64-grid groups than the chip has CUs, up to GNS_MAX_TEAM workgroups (on different CUs) share
@@ -204,5 +205,50 @@ static inline void gns_bwd_layout(int N, int E, int d, int h, int K, int multi, 
   B->off_part = o;  o = gns_align256(o + (size_t)GNS_RED_PARTS * B->slab_floats * 4);
   B->off_tmp = o;   o = gns_align256(o + (size_t)B->slab_floats * 4);
   B->off_team = o;  o = gns_align256(o + (team > 1 ? gns_team_bytes(B->groups) : 0));
+  B->total = o;
+}
+
+// ---- split backward (bwd_variant 4): one kernel sequence per reverse step instead of one persistent kernel -----------------
+// Per step k = K-1..0:  gns_bwds_phys_kernel (one 16-wave workgroup per 64-grid group: Pb-0, the lambda adjoint, the line
+// phase and the per-bus gather) and gns_bwds_sweep_kernel (independent ONE-WAVE workgroups, one per (family, bus chunk,
+// block of R groups); no barrier of any kind).  The three families of a step no longer add into one latent-adjoint row in
+// turn: each writes its own part and the reader sums the parts in the old order, so they can run side by side and nothing
+// has to meet at a counter in HBM - there are no teams in this variant.
+//   adjoint rows per bus:  A0 (vbar, thbar, dpbar, 2 Gs v) | X[3] input-adjoint sums of L_theta, L_v, L_m |
+//                          M[2 step parities][3 families][mq] parts of the latent adjoint
+#define GNS_BWDS_PHYS_WAVES 16
+struct GnsBwdsLayout {
+  int64_t groups, mq, adj_rows, slab_floats;
+  int C;                   // bus chunks per group (partition table for C waves)
+  int R;                   // groups per sweep workgroup (accumulator tiles stay in registers across them)
+  int64_t gblocks;         // ceil(groups / R)
+  int64_t nslab;           // gblocks * C, one slab per (group block, chunk); every (family, step) block is stored exactly once
+  size_t off_adj, off_slots, off_slab, off_part, off_tmp, total;
+};
+static inline void gns_bwds_layout(int N, int E, int d, int h, int K, int multi, int64_t Bt, int ncu, int chunks, GnsBwdsLayout* B) {
+  GnsFamilies f; gns_families(d, h, K, multi, &f);
+  B->groups = (Bt + GNS_LANES - 1) / GNS_LANES;
+  B->mq = (d + 3) / 4;
+  B->adj_rows = 4 + 6 * B->mq;
+  B->slab_floats = (f.g_total + 63) / 64 * 64;
+  if (ncu <= 0) ncu = 256;
+  // a sweep kernel should put 8 one-wave workgroups on every CU (two per SIMD: more were measured slower, the sweeps are bound
+  // by the rows they stream): 8 bus chunks per group when there is a group per CU, finer chunks for smaller batches, several
+  // groups per workgroup for larger ones
+  const int64_t slots = 8LL * ncu;
+  B->C = B->groups * 8 >= slots ? 8 : (B->groups * 16 >= slots ? 16 : 32);
+  B->R = (int)((B->groups * B->C) / slots);
+  if (B->R < 1) B->R = 1;
+  if (chunks > 0 && gns_part_index(chunks) >= 0) B->C = chunks;             // explicit ("bwds_chunks")
+  B->R = (int)((B->groups * B->C) / slots);
+  if (B->R < 1) B->R = 1;
+  B->gblocks = (B->groups + B->R - 1) / B->R;
+  B->nslab = B->gblocks * B->C;
+  size_t o = 0;
+  B->off_adj = o;   o = gns_align256(o + (size_t)B->groups * N * B->adj_rows * GNS_LANES * 16);
+  B->off_slots = o; o = gns_align256(o + (size_t)B->groups * 6 * E * GNS_LANES * 4);
+  B->off_slab = o;  o = gns_align256(o + (size_t)B->nslab * B->slab_floats * 4);
+  B->off_part = o;  o = gns_align256(o + (size_t)GNS_RED_PARTS * B->slab_floats * 4);
+  B->off_tmp = o;   o = gns_align256(o + (size_t)B->slab_floats * 4);
   B->total = o;
 }

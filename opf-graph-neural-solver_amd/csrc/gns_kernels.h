@@ -80,3 +80,25 @@ int gns_launch_forward(int d, int h, int multi, const GnsFwdArgs& A, int threads
 int gns_launch_pack_params(const float* flat, float* pt, float* pn, const GnsFamilies& fam, int K, int D, int H, hipStream_t st);
 int gns_launch_pack_inputs(const int* topo, const float* buses, const float* lines, const float* gens, float* out, int N,
                            int E, int Gn, long long Bt, long long groups, hipStream_t st);
+
+// split backward (gns_backward_split.hip; gns_common.h "split backward")
+struct GnsBwdsArgs {
+  const int* topo;
+  const float* pt; const float* pn;
+  const float* in; const float* state; const float* lam; const float* msg;
+  const float* g_total; const float* g_last; const float* g_v; const float* g_theta;
+  float* adj; float* slots; float* slab;
+  long long t_off[6], t_sz[6], n_off[6], n_sz[6], g_off[6], g_sz[6];
+  long long Bt, G, slab_floats;
+  float gwk;               // gamma^(K-k) of the step being reversed
+  int N, E, K, k;
+  int C, part_idx, R;      // sweep: bus chunks per group, their partition table, groups per workgroup
+  int RB, RBA;             // state rows per bus (1 + mq), adjoint rows per bus (4 + 6 mq)
+  int use_plane;           // phys: (v, theta, dpbar) of all buses in three LDS planes
+  int mode;                // sweep kernels per step: 0 {m}{theta}{v}, 1 {m}{theta+v}, 2 {m+theta+v} (gns_backward_split.hip)
+};
+int gns_bwds_supported(int d, int h, int multi);
+size_t gns_bwds_phys_lds(int N, int* use_plane);
+int gns_launch_bwds_phys(const GnsBwdsArgs& A, size_t lds, hipStream_t st);
+int gns_launch_bwds_sweep(int d, int h, const GnsBwdsArgs& A, hipStream_t st);
+int gns_bwds_init_device();

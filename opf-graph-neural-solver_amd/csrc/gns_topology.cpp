@@ -107,7 +107,7 @@ int build(int N, int E, int Gn, const int32_t* src, const int32_t* dst, const in
   // (waves of a workgroup do not run at equal speed: VALU issue favours the older waves of a SIMD, so the youngest four
   //  finish last whatever they are given; weighting their share down was measured slower, the SIMD total is what counts)
   for (int n = 0; n < N; ++n) pcost[n] = 60.0 + 130.0 * (in_ptr[n + 1] - in_ptr[n]) + 80.0 * (out_ptr[n + 1] - out_ptr[n]);
-  const int wopts[GNS_NPART] = {1, 2, 4, 8, 16, 32};
+  const int wopts[GNS_NPART] = {1, 2, 4, 8, 16, 32, 12, 24};
   for (int i = 0; i < GNS_NPART; ++i) {
     balanced_ranges(cost, wopts[i], &part[i * (GNS_MAXP + 1)]);
     balanced_ranges(ecost, wopts[i], &epart[i * (GNS_MAXP + 1)]);

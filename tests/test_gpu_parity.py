@@ -64,18 +64,23 @@ def test_single_grid_2d_api_and_cpu_inputs(name):
     assert_close(tot, g['total_loss'][0], REL, what='total')
 
 
-@pytest.fixture(params=['matrix-pipe', 'matrix-pipe-background-chains', 'matrix-pipe-wide-records', 'packed-fma'])
+@pytest.fixture(params=['matrix-pipe', 'split-kernels', 'split-kernels-per-family', 'split-kernels-bus-major', 'matrix-pipe-background-chains',
+                        'matrix-pipe-wide-records', 'packed-fma'])
 def dw_engine(request):
     """The weight-gradient paths of the lane-per-grid backward kernel (gns_set_option "dw_mfma", "bwd_variant"): matrix pipe
-    with the layer-wise sweep and sub-record windows, the same with the contraction chains issued behind the weight streams,
-    matrix pipe with wide half-wave records, packed-FMA tiles."""
+    with the layer-wise sweep and sub-record windows, the same sweep as one kernel sequence per reverse step (bwd_variant 4,
+    gns_backward_split.hip), the same with the contraction chains issued behind the weight streams, matrix pipe with wide
+    half-wave records, packed-FMA tiles."""
     import opf_graph_neural_solver_amd as amd
-    old = amd.get_option('dw_mfma'), amd.get_option('bwd_variant'), amd.get_option('train_mapping')
+    old = amd.get_option('dw_mfma'), amd.get_option('bwd_variant'), amd.get_option('train_mapping'), amd.get_option('bwds_mode')
     amd.set_option('train_mapping', 1)                 # (small batches would otherwise go to the grid-per-workgroup pair)
     amd.set_option('dw_mfma', 0 if request.param == 'packed-fma' else 1)
-    amd.set_option('bwd_variant', {'matrix-pipe-wide-records': 1, 'matrix-pipe-background-chains': 3}.get(request.param, 2))
+    split = request.param.startswith('split-kernels')  # bwds_mode: sweep kernels per step {m}{theta+v} | {m}{theta}{v} | {m+theta+v}
+    amd.set_option('bwd_variant', 4 if split else {'matrix-pipe-wide-records': 1, 'matrix-pipe-background-chains': 3}.get(request.param, 2))
+    if split:
+        amd.set_option('bwds_mode', {'split-kernels': 1, 'split-kernels-per-family': 0, 'split-kernels-bus-major': 2}[request.param])
     yield request.param
-    amd.set_option('dw_mfma', old[0]); amd.set_option('bwd_variant', old[1]); amd.set_option('train_mapping', old[2])
+    amd.set_option('dw_mfma', old[0]); amd.set_option('bwd_variant', old[1]); amd.set_option('train_mapping', old[2]); amd.set_option('bwds_mode', old[3])
 
 
 @pytest.mark.parametrize('name', shallow_golden_names())

@@ -8,7 +8,7 @@ SRC=${SRC:-gns_backward}
 F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -ffp-contract=off -Wno-unused-function"
 name=$1; shift
 OBJS=""
-for o in gns_forward gns_backward gns_gridwg gns_gridwg_bwd gns_api; do
+for o in gns_forward gns_backward gns_backward_split gns_gridwg gns_gridwg_bwd gns_api; do
   if [ "$o" = "$SRC" ]; then OBJS="$OBJS /tmp/var_$name.o"; else OBJS="$OBJS $o.o"; fi
 done
 hipcc $F "$@" -Rpass-analysis=kernel-resource-usage -c $SRC.hip -o /tmp/var_$name.o 2> /tmp/var_$name.remarks || { cat /tmp/var_$name.remarks | grep -v remark | head -40; exit 1; }

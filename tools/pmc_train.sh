@@ -21,8 +21,8 @@ import csv, glob, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob('$OUT/p*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r['Kernel_Name'].split('(')[0]
-        if 'gns_' in k and ('forward' in k or 'backward' in k):
+        k = r['Kernel_Name'].split('(')[0].replace('void ', '')
+        if 'gns_' in k and ('forward' in k or 'backward' in k or 'bwds' in k):
             agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
 with open('$OUT/summary.txt', 'w') as o:
     for k in sorted(agg):
