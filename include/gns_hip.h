@@ -106,6 +106,18 @@ int gns_backward(const gns_config* cfg, const void* topo_dev, const float* param
                  const float* grad_total, const float* grad_last, const float* grad_v, const float* grad_theta,
                  float* grad_params, void* bwd_workspace, size_t bwd_workspace_bytes, void* stream);
 
+/* Teams (lane-per-grid kernels, batches with fewer 64-grid groups than CUs: "team" option below) meet at counters in the workspace.
+ * A barrier whose partner workgroup never becomes resident - another kernel or process holds its CU - gives up after ~seconds; the
+ * losses of that call are NaN and the workspace's status word is set.  gns_team_status reads that word: *status = 1 if a team gave
+ * up during the gns_forward that used `fwd_workspace` (same cfg, Bt, save_state), else 0.  It is the ONE entry point that
+ * synchronises (it waits for `stream`, then copies one word); it returns 0 without touching the device when the call did not use
+ * teams.  The host wrapper asks before it launches a backward, so that no gradient of invalid losses reaches an optimiser. */
+int gns_team_status(const gns_config* cfg, int64_t Bt, const void* fwd_workspace, size_t fwd_workspace_bytes, int save_state,
+                    int* status, void* stream);
+/* Byte offset of the status word inside the forward workspace; (size_t)-1 when this (cfg, Bt, save_state) runs without teams, i.e.
+ * when there is nothing to check.  Host code only, no device access. */
+int gns_team_status_offset(const gns_config* cfg, int64_t Bt, int save_state, size_t* offset);
+
 /* The optimiser update of the reference's training loop (optimizer.step() at GNS/main.py:290 with torch.optim.Adam,
  * main.py:241-243: no weight decay, no amsgrad) on the ONE flat parameter buffer, in one launch:
  *   m = m + (g - m)(1 - beta1);  v = beta2 v + (1 - beta2) g^2;
@@ -114,6 +126,13 @@ int gns_backward(const gns_config* cfg, const void* topo_dev, const float* param
  * doubles like torch's (1 - beta is formed in double, then rounded to the float the kernel multiplies with). */
 int gns_adam_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                   double lr, double beta1, double beta2, double eps, int64_t step, void* stream);
+
+/* gns_adam_step with the step counter in device memory - for a training step captured into a HIP graph (a captured launch bakes
+ * its scalar arguments in; Adam's bias corrections change every step).  step_state: 4 floats on the device, caller-owned, zero
+ * before the first step: [0] steps taken so far, [1..2] scratch of the current step.  Every call advances [0] by one.  Two
+ * launches on `stream`, no synchronisation: capturable.  The same arithmetic as gns_adam_step (corrections formed in double). */
+int gns_adam_step_dev(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                      double lr, double beta1, double beta2, double eps, float* step_state, void* stream);
 
 /* ---- diagnostics (benchmarks only; not on the reference's interface) -------------------------------
  * gns_profile_enable(capacity > 0): from now on gns_forward / gns_backward record a HIP event pair around
@@ -134,12 +153,18 @@ int gns_profile_read(int backward, float* ms_sum, int* launches);
  *   "fwd_waves"   waves per workgroup of the lane-per-grid forward (1,2,4,8,16)
  *   "fwd_plane"   LDS planes of the lane-per-grid forward: 0 none (neighbour (v, theta) gathered from HBM) | 1 the (v, theta) plane |
  *                 2 (default) also (delta_p, delta_q) between the physics and the lambda phase of a step
- *   "bwd_variant" family sweep of the lane-per-grid backward: 1 wide half-wave records | 2 layer-wise sweep with sub-record
- *                 windows (default) | 3 = 2 with the contraction chains issued behind the weight streams
+ *   "bwd_variant" lane-per-grid backward: one persistent kernel with 1 wide half-wave records | 2 layer-wise sweep with sub-record
+ *                 windows | 3 = 2 with the contraction chains issued behind the weight streams; 4 (default, three-phi models on the
+ *                 matrix pipe) one kernel sequence per reverse step: no teams, no spin-waits (gns_backward_split.hip)
+ *   "bwds_mode"   sweep kernels per reverse step of variant 4: 0 one per family | 1 (default) {L_m} {L_theta + L_v} | 2 all three
+ *                 families of a bus in one kernel
+ *   "bwds_chunks" bus chunks per 64-grid group of variant 4's sweeps: 0 auto | 8 | 12 | 16 | 24 | 32
  *   "dw_mfma"     0: weight-gradient contraction on packed FMAs instead of the fp32 matrix pipe
  *   "team"        lane-per-grid kernels, batches with fewer 64-grid groups than CUs: workgroups per group, 0 auto (as many
- *                 as keep every workgroup resident) | 1 none | 2 | 4.  Teams meet at counters in the workspace; two team
- *                 kernels in flight at once on one device may starve each other (bounded: NaN results, never a hang)
+ *                 as keep every workgroup resident by the kernel's own occupancy at that launch configuration) | 1 none | 2 | 4.
+ *                 Teams meet at counters in the workspace and need the device to themselves: a kernel of another stream or
+ *                 process holding a partner's CU makes a barrier give up (bounded: NaN losses + gns_team_status, never a hang).
+ *                 Only the forward uses them by default (the default backward, variant 4, has none).
  * Both mappings and both engines compute the same function of the reference (GNS/main.py:140-202, :288). */
 int gns_set_option(const char* name, int value);
 int gns_get_option(const char* name, int* value);

@@ -55,13 +55,17 @@ def load_library():
     lib.gns_prepack.argtypes = [cfgp, vp, vp, vp, vp, i64, vp, sz, vp]
     lib.gns_backward.argtypes = [cfgp, vp, vp, vp, vp, vp, i64, vp, vp, sz, vp, vp, vp, vp, vp, vp, sz, vp]
     lib.gns_adam_step.argtypes = [vp, vp, vp, vp, i64, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, i64, vp]
+    lib.gns_adam_step_dev.argtypes = [vp, vp, vp, vp, i64, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, vp, vp]
+    lib.gns_team_status_offset.argtypes = [cfgp, i64, ctypes.c_int, ctypes.POINTER(sz)]
+    lib.gns_team_status.argtypes = [cfgp, i64, vp, sz, ctypes.c_int, ctypes.POINTER(ctypes.c_int), vp]
     lib.gns_profile_enable.argtypes = [ctypes.c_int]
     lib.gns_profile_read.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]
     lib.gns_set_option.argtypes = [ctypes.c_char_p, ctypes.c_int]
     lib.gns_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
     for f in ('gns_profile_enable', 'gns_profile_read', 'gns_param_count', 'gns_config_supported', 'gns_topology_bytes', 'gns_prepare_topology',
               'gns_workspace_bytes', 'gns_forward', 'gns_backward', 'gns_profile_enable', 'gns_profile_read',
-              'gns_set_option', 'gns_get_option', 'gns_prepack_bytes', 'gns_prepack', 'gns_uses_packed_inputs', 'gns_adam_step'):
+              'gns_set_option', 'gns_get_option', 'gns_prepack_bytes', 'gns_prepack', 'gns_uses_packed_inputs', 'gns_adam_step',
+              'gns_adam_step_dev', 'gns_team_status', 'gns_team_status_offset'):
         getattr(lib, f).restype = ctypes.c_int
     _LIB = lib
     return lib
@@ -69,7 +73,8 @@ def load_library():
 
 EXPORTS = ('gns_version', 'gns_param_count', 'gns_config_supported', 'gns_topology_bytes', 'gns_prepare_topology',
            'gns_workspace_bytes', 'gns_forward', 'gns_backward', 'gns_profile_enable', 'gns_profile_read',
-           'gns_set_option', 'gns_get_option', 'gns_prepack_bytes', 'gns_prepack', 'gns_uses_packed_inputs', 'gns_adam_step')
+           'gns_set_option', 'gns_get_option', 'gns_prepack_bytes', 'gns_prepack', 'gns_uses_packed_inputs', 'gns_adam_step',
+           'gns_adam_step_dev', 'gns_team_status', 'gns_team_status_offset')
 
 
 def set_option(name: str, value: int) -> None:

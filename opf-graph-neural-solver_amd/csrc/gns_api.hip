@@ -20,11 +20,12 @@ struct GnsTuning {
   int team;          // GNS_TEAM: workgroups per 64-grid group of the lane mapping when the batch leaves CUs idle: 0 auto, 1 none, 2, 4
   int ncu;           // compute units of the device (teams must be resident all at once)
   int split_ready;   // gns_bwds_init_device() succeeded
+  int fwd_ready;     // gns_fwd_init_device() succeeded (the lane-per-grid forward may use more than 64 KB of dynamic LDS)
   int bwds_mode;     // GNS_BWDS_MODE: sweep kernels per reverse step of the split backward: 0 one per family, 1 {L_m} {L_theta + L_v}, 2 all three families per bus in one kernel
   int bwds_chunks;   // GNS_BWDS_CHUNKS: bus chunks per 64-grid group of the split backward's sweeps (0 = auto: 12, 24 or 32)
 };
 GnsTuning make_tuning() {
-  GnsTuning t{0, 0, GNS_FWD_THREADS / 64, 2, 1, 0, 0, 4, 0, 0, 0, 1, 0};
+  GnsTuning t{0, 0, GNS_FWD_THREADS / 64, 2, 1, 0, 0, 4, 0, 0, 0, 0, 1, 0};
   {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) t.ncu = n;
@@ -42,6 +43,7 @@ GnsTuning make_tuning() {
   if (const char* e = std::getenv("GNS_TRAIN_MAPPING")) t.train_mapping = !std::strcmp(e, "lane") ? 1 : (!std::strcmp(e, "lds") ? 2 : 0);
   t.gw_ready = (gns_gw_init_device() == GNS_OK && gns_gw_backward_init_device() == GNS_OK) ? 1 : 0;
   t.split_ready = gns_bwds_init_device() == GNS_OK ? 1 : 0;
+  t.fwd_ready = gns_fwd_init_device() == GNS_OK ? 1 : 0;
   return t;
 }
 GnsTuning& tuning() {
@@ -265,6 +267,44 @@ extern "C" int gns_uses_packed_inputs(const gns_config* cfg, int64_t Bt, int sav
   return (save_state ? gw_train_pack(cfg, Bt) : gw_eval_pack(cfg)) > 0 ? 0 : 1;
 }
 
+// Did a team of workgroups give up at a barrier during the gns_forward that used this workspace?  (Teams: lane-per-grid kernels on a
+// batch with fewer 64-grid groups than CUs; a barrier gives up after ~seconds when a partner workgroup never became resident -
+// another kernel or process holding its CU.  The losses of that call are NaN; this is how the host learns it without looking at
+// them.)  The ONE entry point that synchronises: it waits for `stream` and copies one word.  *status = 0 without touching the
+// device when this (cfg, Bt) does not use teams.
+// Byte offset of that status word inside the forward workspace, or (size_t)-1 in *offset when this (cfg, Bt, save_state) runs
+// without teams.  (Tests inject a failure through it; the host wrapper asks it whether a status has to be checked at all.)
+extern "C" int gns_team_status_offset(const gns_config* cfg, int64_t Bt, int save_state, size_t* offset) {
+  int rc = check_cfg(cfg);
+  if (rc != GNS_OK) return rc;
+  if (!offset || Bt <= 0) return GNS_EINVAL;
+  *offset = (size_t)-1;
+  if (lane_team(Bt) <= 1) return GNS_OK;
+  if ((save_state ? gw_train_pack(cfg, Bt) : gw_eval_pack(cfg)) > 0) return GNS_OK;          // the grid-per-workgroup kernels have no teams
+  GnsFwdLayout L;
+  gns_fwd_layout(cfg->n_bus, cfg->n_line, cfg->latent_dim, cfg->hidden_dim, cfg->K, cfg->multiple_phi, Bt, save_state, &L);
+  *offset = L.off_team + GNS_TEAM_STATUS_WORD * 4;
+  return GNS_OK;
+}
+
+extern "C" int gns_team_status(const gns_config* cfg, int64_t Bt, const void* fwd_workspace, size_t fwd_workspace_bytes, int save_state,
+                               int* status, void* stream) {
+  int rc = check_cfg(cfg);
+  if (rc != GNS_OK) return rc;
+  if (!status || !fwd_workspace || Bt <= 0) return GNS_EINVAL;
+  *status = 0;
+  if (lane_team(Bt) <= 1) return GNS_OK;
+  if ((save_state ? gw_train_pack(cfg, Bt) : gw_eval_pack(cfg)) > 0) return GNS_OK;          // the grid-per-workgroup kernels have no teams
+  GnsFwdLayout L;
+  gns_fwd_layout(cfg->n_bus, cfg->n_line, cfg->latent_dim, cfg->hidden_dim, cfg->K, cfg->multiple_phi, Bt, save_state, &L);
+  if (fwd_workspace_bytes < L.total) return GNS_ESIZE;
+  unsigned word = 0;
+  if (hipMemcpyAsync(&word, (const char*)fwd_workspace + L.off_team + GNS_TEAM_STATUS_WORD * 4, 4, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+      hipStreamSynchronize((hipStream_t)stream) != hipSuccess) { (void)hipGetLastError(); return GNS_ELAUNCH; }
+  *status = word ? 1 : 0;
+  return GNS_OK;
+}
+
 extern "C" int gns_prepack_bytes(const gns_config* cfg, int64_t Bt, size_t* bytes) {
   int rc = check_cfg(cfg);
   if (rc != GNS_OK) return rc;
@@ -358,14 +398,30 @@ extern "C" int gns_forward(const gns_config* cfg, const void* topo_dev, const fl
   for (int i = 0; i < fam.nfam; ++i) { A.t_off[i] = fam.t_off[i]; A.t_sz[i] = fam.t_sz[i]; }
   for (int k = 0; k < K; ++k) A.gw[k] = (float)std::pow((double)cfg->gamma, (double)(K - k));   // main.py:198
   A.Bt = Bt; A.G = L.groups; A.N = N; A.E = E; A.K = K; A.save = save_state ? 1 : 0;
-  A.team = lane_team(Bt);
+  const int team0 = lane_team(Bt);
+  A.team = team0;
   A.team_ws = (unsigned char*)(ws + L.off_team);
   int waves = T.fwd_waves;
   while (waves * A.team > GNS_MAXP) waves /= 2;
   A.part_idx = gns_part_index(waves * A.team);
-  A.plane = (gns_fwd_plane_fits(N, A.team) && T.fwd_plane) ? 1 : 0;
-  if (A.plane && gns_fwd_plane2_fits(N, A.team) && T.fwd_plane == 2) A.plane = 2;
-  if (A.team > 1 && hipMemsetAsync(A.team_ws, 0, (size_t)L.groups * GNS_TEAM_CTR_BYTES, st) != hipSuccess) return GNS_ELAUNCH;
+  auto pick_planes = [&]() {
+    A.plane = (T.fwd_ready && gns_fwd_plane_fits(N, A.team) && T.fwd_plane) ? 1 : 0;
+    if (A.plane && gns_fwd_plane2_fits(N, A.team) && T.fwd_plane == 2) A.plane = 2;
+  };
+  pick_planes();
+  if (A.team > 1) {
+    // every workgroup of every team must be resident at once: the kernel's own occupancy at this launch configuration says
+    // how many a CU holds (not just the CU count); a configuration that does not fit runs one workgroup per group instead
+    const int per_cu = gns_fwd_blocks_per_cu(d, h, cfg->multiple_phi, A, waves * 64);
+    if ((long long)per_cu * T.ncu < A.G * A.team) {
+      A.team = 1;
+      waves = T.fwd_waves;
+      A.part_idx = gns_part_index(waves);
+      pick_planes();
+    }
+  }
+  // (the counters - and the status word gns_team_status reads - are zeroed whenever this batch size is one that may use teams)
+  if (team0 > 1 && hipMemsetAsync(A.team_ws, 0, (size_t)L.groups * GNS_TEAM_CTR_BYTES, st) != hipSuccess) return GNS_ELAUNCH;
   prof_mark(0, true, st);
   rc = gns_launch_forward(d, h, cfg->multiple_phi, A, waves * 64, st);
   prof_mark(0, false, st);
@@ -515,5 +571,37 @@ extern "C" int gns_adam_step(float* params, const float* grad, float* exp_avg, f
   hipLaunchKernelGGL(gns_adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grad, exp_avg,
                      exp_avg_sq, (long long)n, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)(lr / bc1),
                      (float)(1.0 / std::sqrt(bc2)), (float)eps);
+  return hipGetLastError() == hipSuccess ? GNS_OK : GNS_ELAUNCH;
+}
+
+// The same update with the step counter ON THE DEVICE, so that a whole training step (forward, backward, this) can be captured
+// into a HIP graph once and replayed: a captured launch bakes its scalar arguments in, and Adam's bias corrections change every
+// step.  state[0] = steps taken so far (a float: exact up to 2^24), state[1..2] = scratch (the step size and 1 / sqrt(1 - beta2^t)
+// of the current step).  Two launches: one thread advances the counter and forms the corrections in double like the host
+// version, then the element-wise kernel reads them.
+__global__ void gns_adam_advance_kernel(float* __restrict__ st, double lr, double b1, double b2) {
+  const double step = (double)st[0] + 1.0;
+  st[0] = (float)step;
+  st[1] = (float)(lr / (1.0 - pow(b1, step)));
+  st[2] = (float)(1.0 / sqrt(1.0 - pow(b2, step)));
+}
+__global__ void gns_adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                    long long n, float one_minus_b1, float b2, float one_minus_b2, const float* __restrict__ st, float eps) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float step_size = st[1], inv_sqrt_bc2 = st[2];
+  const float gi = g[i];
+  const float mi = m[i] + (gi - m[i]) * one_minus_b1;
+  const float vi = b2 * v[i] + one_minus_b2 * gi * gi;
+  m[i] = mi; v[i] = vi;
+  p[i] -= step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+}
+
+extern "C" int gns_adam_step_dev(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                 double lr, double beta1, double beta2, double eps, float* step_state, void* stream) {
+  if (!params || !grad || !exp_avg || !exp_avg_sq || !step_state || n <= 0) return GNS_EINVAL;
+  hipLaunchKernelGGL(gns_adam_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_state, lr, beta1, beta2);
+  hipLaunchKernelGGL(gns_adam_dev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grad, exp_avg,
+                     exp_avg_sq, (long long)n, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), step_state, (float)eps);
   return hipGetLastError() == hipSuccess ? GNS_OK : GNS_ELAUNCH;
 }

@@ -896,6 +896,8 @@ __global__ void __launch_bounds__(GNS_BWD_THREADS) gns_backward_kernel(GnsBwdArg
     team_barrier(team);
   }
   if (team_failed && lane == 0) slab[0] = __builtin_nanf("");          // a team barrier gave up: the gradients must not look valid
+  if (tsize > 1 && team_failed && threadIdx.x == 0)                    // ... and the host can ask (gns_team_status)
+    __hip_atomic_store(reinterpret_cast<unsigned*>(A.team_ws) + GNS_TEAM_STATUS_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // The eight per-wave slabs of this workgroup are summed here, in wave order, into the first one (they are still in this
   // CU's L1 / the XCD's L2): the reduction kernels then read one slab per workgroup instead of eight (121 MB -> 15 MB).
   __syncthreads();

@@ -77,6 +77,7 @@ static inline int gns_team_size(int64_t groups, int ncu, int want) {
   return c;
 }
 // per group: one 64-byte line holding the arrival counter + the partial sums [2 parities][GNS_MAXP waves][64 lanes][2]
+#define GNS_TEAM_STATUS_WORD 3      // word of the FIRST group's counter line: set to 1 by a workgroup whose team barrier gave up
 #define GNS_TEAM_CTR_BYTES 64
 #define GNS_TEAM_RED_FLOATS (2 * GNS_MAXP * GNS_LANES * 2)
 static inline size_t gns_team_bytes(int64_t groups) { return (size_t)groups * (GNS_TEAM_CTR_BYTES + (size_t)GNS_TEAM_RED_FLOATS * 4); }

@@ -514,23 +514,48 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
     A.total_out[b] = t;
     A.last_out[b] = l;
   }
+  // ... and visibly: the status word of the team workspace (word 3 of its first counter line, zeroed with the counters before
+  // the launch) is what gns_team_status hands to the host, so that no gradient of these losses is ever applied
+  if (tsize > 1 && team_failed && threadIdx.x == 0)
+    __hip_atomic_store(reinterpret_cast<unsigned*>(A.team_ws) + GNS_TEAM_STATUS_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+static size_t fwd_dyn_lds(const GnsFwdArgs& A) {
+  return (A.plane ? (size_t)A.N * GNS_LANES * sizeof(f2) : 0) * (A.plane == 2 ? 2 : 1) + (A.team == 1 ? (size_t)GNS_FWD_RED_BYTES : 0);
 }
 
 template <int D, int H, bool MULTI>
 static int launch_forward_t(const GnsFwdArgs& A, int threads, hipStream_t st) {
-  const size_t dyn = (A.plane ? (size_t)A.N * GNS_LANES * sizeof(f2) : 0) * (A.plane == 2 ? 2 : 1) + (A.team == 1 ? (size_t)GNS_FWD_RED_BYTES : 0);
-  static bool attr_ok[64] = {};                                      // > 64 KB of dynamic LDS needs the opt-in, once per kernel and device
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (dyn > 64 * 1024 && !attr_ok[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gns_forward_kernel<D, H, MULTI>), hipFuncAttributeMaxDynamicSharedMemorySize, GNS_FWD_DYN_LDS_MAX) != hipSuccess) {
-      (void)hipGetLastError();
-      return GNS_ELAUNCH;
-    }
-    attr_ok[dev] = true;
-  }
-  hipLaunchKernelGGL((gns_forward_kernel<D, H, MULTI>), dim3((unsigned)(A.G * A.team)), dim3(threads), dyn, st, A);
+  // (> 64 KB of dynamic LDS needs an opt-in per kernel and device: gns_fwd_init_device, once, from the library's initialisation)
+  hipLaunchKernelGGL((gns_forward_kernel<D, H, MULTI>), dim3((unsigned)(A.G * A.team)), dim3(threads), fwd_dyn_lds(A), st, A);
   return hipGetLastError() == hipSuccess ? GNS_OK : GNS_ELAUNCH;
+}
+
+// One-time device initialisation (called under the library's thread-safe one-time initialisation, never inside a capture)
+int gns_fwd_init_device() {
+  int rc = GNS_OK;
+#define GNS_CASE(DD, HH)                                                                                                              \
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gns_forward_kernel<DD, HH, true>), hipFuncAttributeMaxDynamicSharedMemorySize, GNS_FWD_DYN_LDS_MAX) != hipSuccess) rc = GNS_ELAUNCH;   \
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gns_forward_kernel<DD, HH, false>), hipFuncAttributeMaxDynamicSharedMemorySize, GNS_FWD_DYN_LDS_MAX) != hipSuccess) rc = GNS_ELAUNCH;
+  GNS_FOR_EACH_DIMS(GNS_CASE)
+#undef GNS_CASE
+  if (rc != GNS_OK) (void)hipGetLastError();
+  return rc;
+}
+
+// Workgroups of this launch configuration that one CU holds at once (teams need every member resident: gns_api.hip)
+int gns_fwd_blocks_per_cu(int d, int h, int multi, const GnsFwdArgs& A, int threads) {
+  int nb = 0;
+#define GNS_CASE(DD, HH)                                                                                                              \
+  if (d == DD && h == HH) {                                                                                                           \
+    const hipError_t e = multi ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gns_forward_kernel<DD, HH, true>, threads, fwd_dyn_lds(A))     \
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gns_forward_kernel<DD, HH, false>, threads, fwd_dyn_lds(A));   \
+    if (e != hipSuccess) { (void)hipGetLastError(); return 0; }                                                                       \
+    return nb;                                                                                                                        \
+  }
+  GNS_FOR_EACH_DIMS(GNS_CASE)
+#undef GNS_CASE
+  return 0;
 }
 
 int gns_launch_forward(int d, int h, int multi, const GnsFwdArgs& A, int threads, hipStream_t st) {

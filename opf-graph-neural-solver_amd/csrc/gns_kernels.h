@@ -77,6 +77,8 @@ int gns_launch_backward(int d, int h, int multi, int mfma, int variant, const Gn
 int gns_launch_reduce(const float* slab, float* part, float* tmp, const float* flat, float* grad, long long nslab, long long sf,
                       const GnsFamilies& fam, int K, int D, int H, hipStream_t st, long long stride = 0);   // stride (floats) between the slabs read; 0: sf
 int gns_launch_forward(int d, int h, int multi, const GnsFwdArgs& A, int threads, hipStream_t st);
+int gns_fwd_init_device();
+int gns_fwd_blocks_per_cu(int d, int h, int multi, const GnsFwdArgs& A, int threads);
 int gns_launch_pack_params(const float* flat, float* pt, float* pn, const GnsFamilies& fam, int K, int D, int H, hipStream_t st);
 int gns_launch_pack_inputs(const int* topo, const float* buses, const float* lines, const float* gens, float* out, int N,
                            int E, int Gn, long long Bt, long long groups, hipStream_t st);

@@ -77,6 +77,17 @@ class _Topology:
         return t
 
 
+def _raise_if_team_failed(lib, cfg, Bt, ws, save_state, dev):
+    st = ctypes.c_int()
+    with torch.cuda.device(dev):
+        _check(lib.gns_team_status(ctypes.byref(cfg), Bt, ws.data_ptr(), ws.numel(), int(save_state), ctypes.byref(st),
+                                   torch.cuda.current_stream(dev).cuda_stream), 'gns_team_status')
+    if st.value:
+        raise GNSError('a team of workgroups gave up at a barrier: a kernel of another stream or process held a partner\'s compute unit, '
+                       'so the losses of this call are NaN and no gradient was computed from them.  Teams need the device to themselves: '
+                       'opf_graph_neural_solver_amd.set_option("team", 1) runs one workgroup per 64-grid group instead')
+
+
 class _GNSFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mod, topo, want_grad, buses, lines, gens, *params):
@@ -102,12 +113,23 @@ class _GNSFunction(torch.autograd.Function):
                                    gens.data_ptr(), Bt, None if packed is None else packed.data_ptr(),
                                    v.data_ptr(), theta.data_ptr(), total.data_ptr(), last.data_ptr(),
                                    ws.data_ptr(), ws.numel(), int(need_grad), stream), 'gns_forward')
+        # Teams of workgroups (lane-per-grid kernels on a batch that leaves CUs idle) can give up at a barrier when another kernel
+        # holds a partner's CU: the losses are then NaN and the workspace carries a status word.  A training call is checked before
+        # its backward is launched (no gradient of invalid losses reaches an optimiser); an evaluation call at the next call of
+        # the module or by ``GNS.check_status()``.
+        off = ctypes.c_size_t()
+        _check(lib.gns_team_status_offset(ctypes.byref(cfg), Bt, int(need_grad), ctypes.byref(off)), 'gns_team_status_offset')
+        uses_teams = off.value != ctypes.c_size_t(-1).value
+        ctx.team_status = uses_teams and need_grad
+        if uses_teams and not need_grad:
+            mod.__dict__['_pending_status'] = (cfg, Bt, ws, dev)
         if need_grad:
             ctx.cfg, ctx.topo, ctx.ws, ctx.flat, ctx.Bt, ctx.bwd_bytes = cfg, topo, ws, flat, Bt, bwd_b.value
             ctx.params = params
             ctx.mod_flat = mod._flat
             ctx.param_versions = tuple(p._version for p in params) + (mod._flat._version,)   # (a flat optimiser writes through the buffer)
             ctx.inputs = (buses, lines, gens)          # the backward of the grid-per-workgroup mapping re-reads them
+            ctx.input_versions = (buses._version, lines._version, gens._version)
             ctx.packed = packed
             ctx.shapes = [p.shape for p in params]
         return v, theta, total, last
@@ -120,7 +142,11 @@ class _GNSFunction(torch.autograd.Function):
         # optimizer.step(), p.add_()) would give silently inconsistent gradients where torch autograd raises
         if tuple(p._version for p in ctx.params) + (ctx.mod_flat._version,) != ctx.param_versions:
             raise GNSError('parameters were modified in place between forward and backward')
+        if tuple(t._version for t in ctx.inputs) != ctx.input_versions:
+            raise GNSError('buses / lines / generators were modified in place between forward and backward')
         dev = flat.device
+        if ctx.team_status and not torch.cuda.is_current_stream_capturing():     # (the check synchronises: not inside a graph capture)
+            _raise_if_team_failed(lib, ctx.cfg, ctx.Bt, ctx.ws, 1, dev)
         grad = torch.zeros_like(flat)
         bws = torch.empty(ctx.bwd_bytes, dtype=torch.uint8, device=dev)
 
@@ -184,14 +210,17 @@ class GNS(nn.Module):
         # host-side state (not parameters / buffers: they must not appear in state_dict)
         self.__dict__['_flat'] = None
         self.__dict__['_topo_cache'] = {}
-        # 'grid0' (default): every call compares the id columns of the FIRST grid with the cached case (one small compare);
-        # the whole batch is compared when a case is first seen.  'always': whole batch on every call.  'first': never again.
-        self.topology_check = 'grid0'
+        # 'always' (default): every call compares the id columns of EVERY grid of the batch with the cached case - one fused
+        # device compare, one flag, one sync - so a batch that mixes topologies raises like it does when a case is first seen.
+        # Opt-ins for loops that have validated their data set themselves (``training.fit`` does): 'grid0' compares the first
+        # grid only, 'first' trusts the cached case of that shape.
+        self.topology_check = 'always'
         self.__dict__['_mirror'] = None
         # True: a batch that is passed again unchanged (same tensors, same versions) is brought into the kernels' input
         # layout once instead of on every call (gns_prepack).  Off by default: the cache keeps the last batch alive.
         self.cache_packed_inputs = False
         self.__dict__['_pack_cache'] = None
+        self.__dict__['_resident'] = None                      # a data set bound by bind_dataset(): packed once, batches are slices of it
         self.__dict__['_plist'] = None                         # cached list(self.parameters()): walking 430 sub-modules costs 0.25 ms
         # True: the backward delivers d loss / d parameters as ONE tensor, ``flat_leaf().grad`` (state_dict order), instead of
         # one ``.grad`` view per parameter: the 6K x 6 AccumulateGrad nodes and views of a step cost more host time than a
@@ -208,10 +237,15 @@ class GNS(nn.Module):
     def _param_list(self):
         """``list(self.parameters())``, cached: the module tree (3 Linear layers in each of up to 6K LearningBlocks) is fixed after
         construction, and the training step asks for this list half a dozen times.  Dropped whenever ``_apply`` (``.to()``,
-        ``.cuda()``, ``.float()``) or ``load_state_dict`` ran; re-validated against the first and last registered parameter."""
+        ``.cuda()``, ``.float()``) or ``load_state_dict`` ran; re-validated against the first and last registered parameter on every
+        use (a parameter replaced in the middle of the tree by hand needs ``model._plist = None``)."""
         pl = self._plist
         if pl is not None:
-            return pl
+            # parameters replaced outside _apply / load_state_dict (``block.linear1.weight = nn.Parameter(...)``) would leave the
+            # list stale: the first and the last registered parameter are looked up directly (no tree walk) and compared
+            first = (self.phi_v if self.multiple_phis else self.phi)['0'].linear1.weight
+            if pl[0] is first and pl[-1] is self.L_m[str(self.K - 1)].linear4.bias:
+                return pl
         pl = list(self.parameters())
         self.__dict__['_plist'] = pl
         return pl
@@ -262,9 +296,81 @@ class GNS(nn.Module):
         mir.copy_(flat, non_blocking=False)
         return mir
 
+    # ---- inputs in the kernels' layout ----------------------------------------------------------------
+    def bind_dataset(self, all_buses, all_lines, all_generators):
+        """Bring a device-resident data set ``[S,N,6] [S,E,7] [S,Gn,7]`` (what ``utils.load_all_grids`` returns, GNS/utils.py:57-68,
+        ``main.py:255``) into the lane-per-grid kernels' input layout ONCE.  Afterwards a batch that is a slice
+        ``all_*[lo:lo+bs]`` of these very tensors with ``lo`` a multiple of 64 (the reference's batches of 128 in order,
+        ``main.py:276-281``) is read from the packed copy - 64-grid groups ``lo/64 ...`` of it - and no input packing kernel runs
+        for it; any other input is packed per call as before.  The id columns of the whole set must be identical (checked).
+        ``unbind_dataset()`` releases the copy (17.6 KB per case118 grid)."""
+        lib = load_library()
+        if not (all_buses.is_cuda and all_lines.is_cuda and all_generators.is_cuda):
+            raise ValueError('bind_dataset needs device-resident tensors')
+        for t in (all_buses, all_lines, all_generators):
+            if t.dim() != 3 or t.dtype != torch.float32 or not t.is_contiguous():
+                raise ValueError('bind_dataset needs contiguous float32 [S,...] tensors')
+        S, N = all_buses.shape[0], all_buses.shape[1]
+        if not (all_lines.shape[0] == all_generators.shape[0] == S) or S == 0:
+            raise ValueError('batch sizes of buses, lines, generators differ (or are zero)')
+        if all_buses.shape[-1] != 6 or all_lines.shape[-1] != 7 or all_generators.shape[-1] != 7:
+            raise ValueError('expected buses[...,6], lines[...,7], generators[...,7] (GNS/utils.py:4-13)')
+        self.__dict__['_resident'] = None
+        old = self.topology_check
+        self.topology_check = 'always'                # the whole set is compared here, once
+        try:
+            topo = self._topology(all_lines, all_generators, N)
+        finally:
+            self.topology_check = old
+        cfg = self._config(N, all_lines.shape[1], all_generators.shape[1])
+        nbytes, gbytes = ctypes.c_size_t(), ctypes.c_size_t()
+        _check(lib.gns_prepack_bytes(ctypes.byref(cfg), S, ctypes.byref(nbytes)), 'gns_prepack_bytes')
+        _check(lib.gns_prepack_bytes(ctypes.byref(cfg), 64, ctypes.byref(gbytes)), 'gns_prepack_bytes')
+        packed = torch.empty(nbytes.value, dtype=torch.uint8, device=all_buses.device)
+        with torch.cuda.device(all_buses.device):
+            _check(lib.gns_prepack(ctypes.byref(cfg), topo.blob.data_ptr(), all_buses.data_ptr(), all_lines.data_ptr(),
+                                   all_generators.data_ptr(), S, packed.data_ptr(), packed.numel(),
+                                   torch.cuda.current_stream(all_buses.device).cuda_stream), 'gns_prepack')
+        tens = (all_buses, all_lines, all_generators)
+        self.__dict__['_resident'] = dict(tensors=tens, versions=tuple(t._version for t in tens), topo=topo, packed=packed,
+                                          group_bytes=gbytes.value, S=S, hits=0)
+
+    def unbind_dataset(self):
+        self.__dict__['_resident'] = None
+
+    def _resident_slice(self, topo, buses, lines, gens):
+        """The packed 64-grid groups of a bound data set that hold this batch, or None when the batch is not an aligned slice of it."""
+        R = self._resident
+        if R is None or R['topo'] is not topo:
+            return None
+        if tuple(t._version for t in R['tensors']) != R['versions']:
+            self.__dict__['_resident'] = None         # the data set was written to: its packed copy is stale
+            return None
+        lo = None
+        for t, r in zip((buses, lines, gens), R['tensors']):
+            if t.device != r.device or t.untyped_storage().data_ptr() != r.untyped_storage().data_ptr() or t.shape[1:] != r.shape[1:]:
+                return None
+            per = r.shape[1] * r.shape[2]
+            d = t.storage_offset() - r.storage_offset()
+            if d < 0 or d % per or not t.is_contiguous():
+                return None
+            if lo is None:
+                lo = d // per
+            elif lo != d // per:
+                return None
+        if lo % 64 or lo + buses.shape[0] > R['S']:
+            return None
+        R['hits'] += 1
+        return R['packed'][(lo // 64) * R['group_bytes']:]
+
     def _packed_inputs(self, lib, cfg, topo, buses, lines, gens, stream, need_grad):
-        if not self.cache_packed_inputs or not lib.gns_uses_packed_inputs(ctypes.byref(cfg), buses.shape[0], int(need_grad)):
+        if not lib.gns_uses_packed_inputs(ctypes.byref(cfg), buses.shape[0], int(need_grad)):
             return None                              # (the grid-per-workgroup kernels read the caller's tensors in place)
+        res = self._resident_slice(topo, buses, lines, gens)
+        if res is not None:
+            return res
+        if not self.cache_packed_inputs:
+            return None
         key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (buses, lines, gens)) + (id(topo),)
         ent = self._pack_cache
         if ent is not None and ent[0] == key:
@@ -277,6 +383,16 @@ class GNS(nn.Module):
         # the entry holds the tensors themselves: their storage cannot be freed and handed to other data while it is cached
         self.__dict__['_pack_cache'] = (key, (buses, lines, gens, topo), packed)
         return packed
+
+    def check_status(self):
+        """Raise ``GNSError`` if the last evaluation-mode call ran teams of workgroups and one of them gave up at a barrier (its losses
+        are NaN).  Synchronises with the device; called automatically at the next call of the module.  Training-mode calls are
+        checked before their backward is launched."""
+        pend = self.__dict__.get('_pending_status')
+        if pend is not None:
+            self.__dict__['_pending_status'] = None
+            cfg, Bt, ws, dev = pend
+            _raise_if_team_failed(load_library(), cfg, Bt, ws, 0, dev)
 
     def flat_leaf(self):
         """A leaf tensor (``requires_grad``) that aliases the flat parameter buffer: with ``flat_grad = True`` the autograd graph
@@ -312,9 +428,10 @@ class GNS(nn.Module):
         if ent is not None and self.topology_check == 'first':
             return ent[0]
         if ent is not None:
-            same = torch.equal(ids_l, ent[1]) and torch.equal(ids_g, ent[2])
-            if same and self.topology_check == 'always':
-                same = bool((lines3[:, :, 0:2] == ids_l).all()) and bool((gens3[:, :, 0] == ids_g).all())
+            if self.topology_check == 'grid0':
+                same = bool(((ids_l == ent[1]).all() & (ids_g == ent[2]).all()).item())
+            else:                                        # the whole batch against the cached ids: one flag, one sync
+                same = bool(((lines3[:, :, 0:2] == ent[1]).all() & (gens3[:, :, 0] == ent[2]).all()).item())
             if same:
                 return ent[0]
         if not (bool((lines3[:, :, 0:2] == ids_l).all()) and bool((gens3[:, :, 0] == ids_g).all())):
@@ -343,6 +460,8 @@ class GNS(nn.Module):
         return t[..., order]
 
     def forward(self, buses, lines, generators, B=None, L=None, G=None):
+        if self.__dict__.get('_pending_status') is not None:
+            self.check_status()
         params = self._ensure_flat()
         dev = params[0].device
         if dev.type != 'cuda':

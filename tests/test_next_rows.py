@@ -151,3 +151,147 @@ def test_counter_based_synthetic_grids_are_keyed_by_global_grid_index():
     assert 0.0 <= float(u.min()) and float(u.max()) < 1.0 and abs(float(u.mean()) - 0.5) < 5e-3
     # balance rescale of augment_grids.py:51: sum(Pd) == sum(Pg) for every grid
     assert torch.allclose(full[0][:, :, 2].sum(1), full[2][:, :, 3].sum(1), rtol=1e-5)
+
+
+def test_flat_optimizer_is_a_torch_optimizer_and_takes_a_scheduler():
+    """lr schedulers (the reference keeps a LambdaLR warm-up commented out, main.py:245-252) must be able to drive the
+    flat optimiser; its param_groups / state are the inner torch optimiser's."""
+    torch.manual_seed(0)
+    m = amd.GNS(10, 10, 2, 0.9, True)
+    opt = amd.training.FlatOptimizer(m, torch.optim.Adam, lr=1e-3)
+    assert isinstance(opt, torch.optim.Optimizer)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda e: 0.5 ** e)
+    w0 = m.flat_parameters().clone()
+    for p in m.parameters():
+        p.grad = torch.ones_like(p)
+    opt.step(); sched.step()
+    assert torch.allclose(w0 - m.flat_parameters(), torch.full_like(w0, 1e-3), rtol=1e-4)      # Adam's first step moves every weight by lr
+    assert opt.param_groups[0]['lr'] == 5e-4 and opt.inner.param_groups[0]['lr'] == 5e-4
+    w1 = m.flat_parameters().clone()
+    for p in m.parameters():
+        p.grad = torch.ones_like(p)
+    opt.step()
+    assert torch.allclose(w1 - m.flat_parameters(), torch.full_like(w0, 5e-4), rtol=1e-3)
+    sd = opt.state_dict()
+    opt.load_state_dict(sd)
+    assert opt.param_groups is opt.inner.param_groups and opt.state is opt.inner.state
+    # frozen parameters: no flat gradient leaf (it would span them), a plain torch optimiser over the trainable ones
+    m2 = amd.GNS(10, 10, 2, 0.9, True)
+    m2.L_v['0'].linear1.weight.requires_grad_(False)
+    o2 = amd.training.make_optimizer(m2, flat=True)
+    assert not isinstance(o2, amd.training.FlatOptimizer) and not m2.flat_grad
+
+
+@pytest.mark.gpu
+def test_graphed_step_replays_equal_eager_steps_at_the_reference_operating_point():
+    """the reference's own run (case14, batch 128, K=15, latent 10, three phis: main.py:209-254) as ONE captured
+    HIP graph per step - forward, mean, backward, reduce / unfold, Adam.  Ten replays leave exactly the weights of ten eager steps."""
+    import time
+    bu, li, ge = amd.synth.synth_grids(14, 128 * 10, seed=5, device='cuda')
+    res = {}
+    for mode in ('eager', 'graph'):
+        torch.manual_seed(0)
+        m = amd.GNS(10, 10, 15, 0.9, True).cuda()
+        opt = amd.training.make_optimizer(m)
+        assert isinstance(opt, amd.training.FlatOptimizer)
+        if mode == 'eager':
+            opt.capturable = True                          # the same device-side step counter the captured step uses
+            m.topology_check = 'first'
+            for i in range(10):
+                sl = slice(128 * i, 128 * (i + 1))
+                amd.training.train_step(m, opt, bu[sl], li[sl], ge[sl])
+            torch.cuda.synchronize()
+            res['eager10'] = m.flat_parameters().clone()
+            t0 = time.perf_counter()
+            for i in range(100):
+                amd.training.train_step(m, opt, bu[:128], li[:128], ge[:128])
+            torch.cuda.synchronize()
+            res['ms_per_eager_step'] = (time.perf_counter() - t0) / 100 * 1e3
+        else:
+            step = amd.training.GraphedStep(m, opt, bu[:128], li[:128], ge[:128])
+            for i in range(10):
+                sl = slice(128 * i, 128 * (i + 1))
+                tot, last = step.run(bu[sl], li[sl], ge[sl])
+            assert step.replays == 10 and bool(torch.isfinite(tot)) and bool(torch.isfinite(last))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(200):
+                step.run(bu[:128], li[:128], ge[:128])
+            torch.cuda.synchronize()
+            res['ms_per_replayed_step'] = (time.perf_counter() - t0) / 200 * 1e3
+    # (the graph model ran 200 more replays for the timing: compare a fresh capture's first ten instead)
+    torch.manual_seed(0)
+    m = amd.GNS(10, 10, 15, 0.9, True).cuda()
+    opt = amd.training.make_optimizer(m)
+    step = amd.training.GraphedStep(m, opt, bu[:128], li[:128], ge[:128])
+    for i in range(10):
+        sl = slice(128 * i, 128 * (i + 1))
+        step.run(bu[sl], li[sl], ge[sl])
+    torch.cuda.synchronize()
+    assert torch.equal(m.flat_parameters(), res['eager10'])
+    print(f"\\n[training step, case14 x 128, K=15, d=10, three phis] eager {res['ms_per_eager_step']:.3f} ms, "
+          f"captured graph {res['ms_per_replayed_step']:.3f} ms per step")
+    assert res['ms_per_replayed_step'] < res['ms_per_eager_step']
+
+
+@pytest.mark.gpu
+def test_fit_reads_a_bound_dataset_without_repacking_and_matches_per_call_packing():
+    """fit() packs the resident data set once (GNS.bind_dataset); every 64-aligned batch of the epochs is read
+    from that copy.  Same bits as the loop that packs each batch on every call."""
+    old = amd.get_option('train_mapping')
+    amd.set_option('train_mapping', 1)                     # the lane-per-grid kernels are the ones that read the packed layout
+    try:
+        bu, li, ge = amd.synth.synth_grids(30, 4 * 512, seed=11, device='cuda')
+        torch.manual_seed(0)
+        a = amd.GNS(20, 10, 3, 0.9, True).cuda()
+        hits = {}
+        orig_unbind = a.unbind_dataset
+        def unbind():
+            hits['n'] = a._resident['hits']
+            orig_unbind()
+        a.unbind_dataset = unbind
+        amd.training.fit(a, bu, li, ge, epochs=3, batch_size=512, log=lambda s: None, graph=False)
+        assert hits['n'] == 4 * 3 * 1 or hits['n'] == 4 * 3                     # one lookup per training forward
+        torch.manual_seed(0)
+        b = amd.GNS(20, 10, 3, 0.9, True).cuda()
+        b.topology_check = 'first'
+        opt = amd.training.make_optimizer(b)
+        for epoch in range(3):
+            for lo in range(0, 2048, 512):
+                amd.training.train_step(b, opt, bu[lo:lo + 512], li[lo:lo + 512], ge[lo:lo + 512])
+        torch.cuda.synchronize()
+        assert torch.equal(a.flat_parameters(), b.flat_parameters())
+        # a batch that is not a 64-aligned slice of the bound set is packed per call as before
+        a.bind_dataset(bu, li, ge)
+        n0 = a._resident['hits']
+        with torch.enable_grad():
+            a(bu[32:32 + 512], li[32:32 + 512], ge[32:32 + 512])[2].mean().backward()
+            a(bu[64:64 + 512].clone(), li[64:64 + 512].clone(), ge[64:64 + 512].clone())[2].mean().backward()
+        assert a._resident['hits'] == n0
+        a(bu[64:64 + 100], li[64:64 + 100], ge[64:64 + 100])[2].mean().backward()   # ragged tail inside the set: lanes beyond it are dead
+        assert a._resident['hits'] == n0 + 1
+        a.unbind_dataset()
+    finally:
+        amd.set_option('train_mapping', old)
+
+
+@pytest.mark.gpu
+def test_default_topology_check_compares_the_whole_batch_and_inputs_are_version_checked():
+    """ADVICE r2: a batch whose FIRST grid matches the cached case but whose other grids do not must raise (default 'always');
+    inputs modified in place between forward and backward must raise like autograd would."""
+    torch.manual_seed(0)
+    m = amd.GNS(20, 10, 2, 0.9, True).cuda()
+    assert m.topology_check == 'always'
+    bu, li, ge = amd.synth.synth_grids(14, 8, seed=2, device='cuda')
+    m(bu, li, ge)
+    bad = li.clone()
+    bad[5, 3, 0], bad[5, 3, 1] = li[5, 3, 1], li[5, 3, 0]        # one line of one grid reversed: another topology
+    with pytest.raises(ValueError):
+        m(bu, bad, ge)
+    m.topology_check = 'grid0'                                   # explicit opt-in: only the first grid is compared
+    m(bu, bad, ge)
+    m.topology_check = 'always'
+    out = m(bu, li, ge)
+    bu.mul_(1.0)                                                 # in-place write bumps the version counter
+    with pytest.raises(amd.GNSError):
+        out[2].mean().backward()
