@@ -25,17 +25,36 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-CASE, BATCH_PER_GPU, K, D, H, GAMMA, MULTI = 118, 16384, 4, 20, 10, 0.9, True
-BYTES_PER_GRID = 10504          # compulsory: every input element read once + every output written once
-MFLOP_FWD_PER_GRID = 4.19216    # nominal MLP flops of one forward (MACs x 2), reference formulation
+# BASELINE.json configs that fit one GPU (per-GPU batch).  --config 3 (default) is the one the metric is quoted on.
+CONFIGS = {
+    2: dict(case=30, batch=4096, K=4, name='configs[1]: case30, batch 4096, K=4 (correctness gate)'),
+    3: dict(case=118, batch=16384, K=4, name='configs[2]: case118, batch 16384, K=4 (the metric; configs[3] = 8 x this)'),
+    5: dict(case=300, batch=8192, K=10, name='configs[4]: case300, batch 65536 on 8 GPUs = 8192 per GPU, K=10, multiple_phi'),
+}
+SHAPES = {14: (14, 20, 5), 30: (30, 41, 6), 118: (118, 186, 54), 300: (300, 411, 69)}      # GNS/utils.py:45-56
+D, H, GAMMA, MULTI = 20, 10, 0.9, True
+CASE, BATCH_PER_GPU, K = 118, 16384, 4          # set from --config in main()
 HBM_PEAK_GBS = 8000.0           # MI355X spec (MI355X_MICROARCH.md)
 FP32_PEAK_TFLOPS = 157.3
 DATA_SEED = 1234
 
 
+def bytes_per_grid(case):
+    """Compulsory bytes: every input element read once + every output written once: 10 504 for case118."""
+    N, E, Gn = SHAPES[case]
+    return 4 * (6 * N + 7 * E + 7 * Gn) + 4 * (2 * N + 2)
+
+
+def mflop_fwd_per_grid(case, k):
+    """Nominal MLP flops of one forward (MACs x 2), the reference's formulation, three phis: 4.19 for case118, K=4."""
+    N, E, Gn = SHAPES[case]
+    macs = k * (E * 3 * ((D + 5) * H + H * H + H * D) + N * (2 * ((4 + 2 * D) * H + H * H + H) + (4 + 2 * D) * H + H * H + H * D))
+    return macs * 2 / 1e6
+
+
 def _cpu_worker(args):
     """One single-threaded process: time the oracle's per-grid forward+backward (and forward only) for ~seconds."""
-    seconds, seed = args
+    seconds, seed, CASE, K = args
     import torch
     torch.set_num_threads(1)
     sys.path.insert(0, ROOT)
@@ -64,7 +83,7 @@ def _cpu_worker(args):
     return out
 
 
-def cpu_baseline(seconds=14.0):
+def cpu_baseline(seconds=14.0, case=118, k=4):
     import multiprocessing as mp
     try:
         cores = len(os.sched_getaffinity(0))
@@ -74,12 +93,12 @@ def cpu_baseline(seconds=14.0):
     cores = max(1, min(cores, 5))
     ctx = mp.get_context('spawn')     # fresh interpreters; the parent has not touched the GPU yet
     with ctx.Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [(seconds, i) for i in range(cores)])
+        res = pool.map(_cpu_worker, [(seconds, i, case, k) for i in range(cores)])
     rate = {m: sum(r[m][0] / r[m][1] for r in res) for m in ('fwd', 'fwd_bwd')}
     grids = sum(r['fwd_bwd'][0] for r in res)
     return {'value': round(rate['fwd_bwd'], 1), 'unit': 'grids/s', 'cores': cores, 'kind': 'port',
             'forward_only_grids_per_s': round(rate['fwd'], 1),
-            'sample': f'{grids} case118 grids (K=4, d=20, h=10, multiple_phi), one grid per call like GNS/main.py:279-288, '
+            'sample': f'{grids} case{case} grids (K={k}, d=20, h=10, multiple_phi), one grid per call like GNS/main.py:279-288, '
                       f'{cores} single-threaded processes x ~{seconds:.0f} s, torch {__import__("torch").__version__} CPU'}
 
 
@@ -105,13 +124,21 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch-per-gpu', type=int, default=BATCH_PER_GPU)
+    ap.add_argument('--config', type=int, default=3, choices=sorted(CONFIGS),
+                    help='BASELINE.json config number (1-based): 3 = case118 x 16384, K=4 (default, the metric); 2 = case30 x 4096; 5 = case300 x 8192 per GPU, K=10')
+    ap.add_argument('--batch-per-gpu', type=int, default=None)
     ap.add_argument('--sustained-steps', type=int, default=2000,
                     help='extra untimed-by-the-contract run reported as "sustained" (0 = skip): the K-step burst ends before the chip settles at its power limit')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--rehearse-cpu', action='store_true',
                     help='launcher / rendezvous / collective / JSON plumbing only, over gloo, without touching a GPU (CPU test)')
     a = ap.parse_args()
+    global CASE, BATCH_PER_GPU, K
+    CASE, BATCH_PER_GPU, K = CONFIGS[a.config]['case'], CONFIGS[a.config]['batch'], CONFIGS[a.config]['K']
+    if a.batch_per_gpu is None:
+        a.batch_per_gpu = BATCH_PER_GPU
+    BYTES_PER_GRID, MFLOP_FWD_PER_GRID = bytes_per_grid(CASE), mflop_fwd_per_grid(CASE, K)
+    NB, NE, NG = SHAPES[CASE]
     if a.gpus < 1:
         raise SystemExit('--gpus must be >= 1')
     launched = 'WORLD_SIZE' in os.environ and 'RANK' in os.environ
@@ -124,7 +151,7 @@ def main():
         raise SystemExit(f'WORLD_SIZE={world} does not match --gpus {a.gpus}')
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.rehearse_cpu:
-        cpu = cpu_baseline()
+        cpu = cpu_baseline(case=CASE, k=K)
 
     import torch
     import torch.distributed as dist
@@ -137,8 +164,8 @@ def main():
         dist.all_reduce(t)
         dist.barrier()
         if rank == 0:
-            print(json.dumps({'metric': 'rehearsal', 'n_gpus': world, 'sum_of_ranks': float(t.item()),
-                              'global_batch': a.batch_per_gpu * world}), flush=True)
+            print(json.dumps({'metric': 'rehearsal', 'n_gpus': world, 'sum_of_ranks': float(t.item()), 'config': a.config,
+                              'workload': CONFIGS[a.config]['name'], 'global_batch': a.batch_per_gpu * world}), flush=True)
         dist.destroy_process_group()
         return
 
@@ -163,13 +190,16 @@ def main():
 
     torch.manual_seed(0)                       # identical replicas on every rank
     model = amd.GNS(latent_dim=D, hidden_dim=H, K=K, gamma=GAMMA, multiple_phi=MULTI).to(dev)
-    model.topology_check = 'first'             # id columns are verified once per case, not on every step
-    model.cache_packed_inputs = True           # the batch stays resident: it is brought into the kernels' input layout once (gns_prepack)
     opt = amd.training.make_optimizer(model)               # the reference's optimiser: Adam, lr 1e-3 (GNS/main.py:241-243)
     bt = a.batch_per_gpu
     # rank r holds grids [r*bt, (r+1)*bt) of ONE data set: the same grids whatever the GPU count
     buses, lines, gens = amd.synth.synth_grids(CASE, bt, seed=DATA_SEED, device=dev, first_index=rank * bt)
     Bc, Lc, Gc = amd.get_BLG()
+    # What training.fit() does with a resident data set (GNS/main.py:255 loads it whole): the id columns of every grid are compared
+    # once and the set is brought into the kernels' input layout once (GNS.bind_dataset -> gns_prepack); the steps then read
+    # that copy.  "ms_per_step_packing_per_call" below is the same step on inputs the model has never seen (packed on every call).
+    model.bind_dataset(buses, lines, gens)
+    model.topology_check = 'first'
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -206,6 +236,13 @@ def main():
     lib.gns_profile_read(1, ctypes.byref(ms_b), ctypes.byref(n_b))
     lib.gns_profile_enable(0)
     final_loss = float(tot.mean().item())
+    packed_hits = model._resident['hits'] if model._resident is not None else 0
+    # the same step without the resident copy: inputs are packed by gns_pack_inputs_kernel inside every forward call
+    model.unbind_dataset()
+    for _ in range(2):
+        step()
+    dt_pack, _ = timed(a.steps)
+    model.bind_dataset(buses, lines, gens)
     sustained = None
     if a.sustained_steps > 0:
         sdt, _ = timed(a.sustained_steps)
@@ -230,6 +267,10 @@ def main():
         train_map = {0: 'auto', 1: 'lane-per-grid', 2: 'grid-per-workgroup'}[amd.get_option('train_mapping')]
         kfwd = 'gns_gw_forward_kernel' if train_map == 'grid-per-workgroup' else 'gns_forward_kernel'
         kbwd = 'gns_gw_backward_kernel' if train_map == 'grid-per-workgroup' else 'gns_backward_kernel'
+        if train_map != 'grid-per-workgroup' and amd.get_option('bwd_variant') == 4:
+            # the split backward: K x (gns_bwds_phys_kernel + the sweep kernels of the mode); timed as ONE unit by the library's
+            # event pair around the whole sequence, which is what the persistent gns_backward_kernel was
+            kbwd = 'gns_backward[split: %d x (gns_bwds_phys_kernel + gns_bwds_sweep_kernel x %d)]' % (K, {0: 3, 1: 2, 2: 1}[amd.get_option('bwds_mode')])
         dom_ms, dom, dom_is_bwd = (bwd_ms, kbwd, True) if bwd_ms >= fwd_ms else (fwd_ms, kfwd, False)
         ach_gbs = BYTES_PER_GRID * bt / (dom_ms * 1e-3) / 1e9
         dom_flop = (2.0 if dom_is_bwd else 1.0) * MFLOP_FWD_PER_GRID * 1e6 * bt
@@ -237,23 +278,29 @@ def main():
         pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(dom)
+                traffic = json.load(open(pmc)).get(f'config{a.config}', {}).get('backward' if dom_is_bwd else 'forward')
                 traffic_src = 'profiles/pmc_traffic.json (static: rocprofv3 PMC run of the same workload, not measured in this run)'
             except Exception:
                 traffic = None
         line = {
-            'metric': 'grids/sec (fwd+bwd) on batched case118, K=4', 'value': round(value, 1), 'unit': 'grids/s',
+            'metric': 'grids/sec (fwd+bwd) on batched case118, K=4' if a.config == 3 else f'grids/sec (fwd+bwd) on batched case{CASE}, K={K}',
+            'value': round(value, 1), 'unit': 'grids/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'case118-shaped grids (118 buses, 186 lines, 54 generators), batch {bt} per GPU, K=4, '
-                                   'latent_dim=20, hidden_dim=10, multiple_phi=True, gamma=0.9; step = fused forward + fused '
+            'config': {'workload': f'BASELINE {CONFIGS[a.config]["name"]}: case{CASE}-shaped grids ({NB} buses, {NE} lines, {NG} generators), '
+                                   f'batch {bt} per GPU, K={K}, latent_dim=20, hidden_dim=10, multiple_phi=True, gamma=0.9; step = fused forward + '
                                    'backward + flat-gradient all-reduce + Adam; grids = counter-based synthetic data set '
                                    f'(seed {DATA_SEED}), rank r holds global grids [r*{bt}, (r+1)*{bt})',
+                       'inputs': f'resident data set, id columns compared and pre-packed ONCE before the timed region (GNS.bind_dataset -> gns_prepack: '
+                                 f'{4 * 4 * (3 * NB + 4 * NE + 1) / 1024:.1f} KB/grid instead of the reference layout\'s {(BYTES_PER_GRID - 4 * (2 * NB + 2)) / 1024:.1f} KB/grid), '
+                                 f'as training.fit() does; {packed_hits} of the timed + warm-up forwards read that copy',
                        'global_batch': bt * world, 'parallelism': f'dp{world} (grid-sharded)', 'training_kernels': train_map},
+            'ms_per_step_packing_per_call': round(dt_pack / a.steps * 1e3, 4),
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': round(ach_gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(ach_gbs / HBM_PEAK_GBS, 5), 'traffic': traffic, 'traffic_source': traffic_src,
                          'algorithmic_bytes_per_launch': BYTES_PER_GRID * bt, 'kernel_ms': round(dom_ms, 4)},
-            'roofline_fp32': {'bound': 'fp32 vector FMA (the binding one: ~400 flop/B)', 'kernel': dom,
+            'roofline_fp32': {'bound': 'fp32 vector FMA (the binding one: ~400 flop/B); NOMINAL flops of the reference formulation (incl. the dead '
+                                       'last-step m family and the unfolded networks the kernels skip)', 'kernel': dom,
                               'achieved': round(dom_flop / (dom_ms * 1e-3) / 1e12, 3), 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                               'frac': round(dom_flop / (dom_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
                               'nominal_flop_per_launch': dom_flop},

@@ -187,12 +187,70 @@ def run_metrics(name, n_samples, n_bus, n_line, seed):
     print(name, 'statements', [n.lineno for n in stats], sorted(k for k in out if k.startswith('ref_')))
 
 
+def run_augment(synth, name, case_nr, n_draws, seed):
+    """Goldens for the synthetic-grid generator.  ``GNS/augment_grids.py`` is a module-level script that imports
+    PYPOWER (absent) and writes 10 000 pickles, so it cannot be run; what CAN be executed are its own statements: the file is
+    parsed (never copied), the nine ``*_range`` assignments (``augment_grids.py:12-20``) and the perturbation statements inside its
+    loop (``:30-53``: only ``np`` calls on ``augmented_case``) are compiled from the parsed tree and run ``n_draws`` times with a
+    seeded numpy generator on a PYPOWER-layout case built from the public IEEE-14 base data.  Stored: the range constants,
+    per-column statistics of the draws relative to the base case, the balance identity of ``:51`` and the first draws."""
+    import ast
+    import copy
+    tree = ast.parse(open(os.path.join(REF, 'augment_grids.py')).read())
+    ranges = [n for n in tree.body if isinstance(n, ast.Assign) and len(n.targets) == 1 and isinstance(n.targets[0], ast.Name)
+              and n.targets[0].id.endswith('_range')]
+    loop = [n for n in tree.body if isinstance(n, ast.For)]
+    assert len(ranges) == 9 and len(loop) >= 1
+    body = []
+    for n in loop[0].body:
+        # the statements that touch augmented_case['bus' | 'branch' | 'gen'] or define pg_min / pg_max; not the list bookkeeping
+        if isinstance(n, ast.Assign) or isinstance(n, ast.AugAssign):
+            tgt = n.targets[0] if isinstance(n, ast.Assign) else n.target
+            names = {x.id for x in ast.walk(tgt) if isinstance(x, ast.Name)}
+            if names & {'augmented_case', 'pg_max', 'pg_min'} and not (isinstance(n, ast.Assign) and isinstance(n.value, ast.Call)
+                                                                   and getattr(n.value.func, 'attr', '') == 'deepcopy'):
+                body.append(n)
+    ns = {'np': np}
+    exec(compile(ast.Module(body=ranges, type_ignores=[]), 'augment_grids.py', 'exec'), ns)
+    code = compile(ast.Module(body=body, type_ignores=[]), 'augment_grids.py', 'exec')
+    c = synth.base_case(case_nr)
+    n, e, gn = synth.CASE_SHAPES[case_nr]
+    bus = np.zeros((n, 13)); bus[:, 0] = np.arange(1, n + 1); bus[:, 2] = c['Pd']; bus[:, 3] = c['Qd']
+    br = np.zeros((e, 13)); br[:, 0] = c['f_bus']; br[:, 1] = c['t_bus']; br[:, 2] = c['r']; br[:, 3] = c['x']; br[:, 4] = c['b']
+    ge = np.zeros((gn, 21)); ge[:, 0] = c['gen_bus']; ge[:, 1] = c['Pg']; ge[:, 5] = c['Vg']; ge[:, 8] = c['Pmax']; ge[:, 9] = c['Pmin']
+    case = {'bus': bus, 'branch': br, 'gen': ge}
+    np.random.seed(seed)
+    cols = {k: [] for k in ('r', 'x', 'b', 'tau', 'shift', 'vg', 'pg', 'pd', 'qd')}
+    for _ in range(n_draws):
+        ns['augmented_case'] = copy.deepcopy(case)
+        exec(code, ns)
+        a = ns['augmented_case']
+        cols['r'].append(a['branch'][:, 2]); cols['x'].append(a['branch'][:, 3]); cols['b'].append(a['branch'][:, 4])
+        cols['tau'].append(a['branch'][:, 8]); cols['shift'].append(a['branch'][:, 9]); cols['vg'].append(a['gen'][:, 5])
+        cols['pg'].append(a['gen'][:, 1]); cols['pd'].append(a['bus'][:, 2]); cols['qd'].append(a['bus'][:, 3])
+    out = {'n_draws': np.array(n_draws), 'stmt_lines': np.array([x.lineno for x in body]),
+           'base_r': c['r'], 'base_x': c['x'], 'base_b': c['b'], 'base_vg': c['Vg'], 'base_pd': c['Pd'], 'base_qd': c['Qd'],
+           'base_pmax': c['Pmax'], 'base_pmin': c['Pmin']}
+    for r_ in ranges:
+        out[r_.targets[0].id] = np.asarray(ns[r_.targets[0].id], dtype=np.float64)
+    for k, v in cols.items():
+        v = np.stack(v)
+        out[k + '_min'], out[k + '_max'], out[k + '_mean'], out[k + '_std'] = v.min(0), v.max(0), v.mean(0), v.std(0)
+        out[k + '_first8'] = v[:8]
+    pd_, pg_ = np.stack(cols['pd']), np.stack(cols['pg'])
+    out['balance_max_rel_err'] = np.array(np.abs(pd_.sum(1) / pg_.sum(1) - 1.0).max())       # augment_grids.py:51
+    np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', name + '.npz'), **out)
+    print(name, 'statements', [x.lineno for x in body], 'ranges', {r_.targets[0].id: ns[r_.targets[0].id] for r_ in ranges},
+          'balance', float(out['balance_max_rel_err']))
+
+
 def main():
     ref = _import_reference()
     synth = _load_pkg()
     run_prepare(synth, 'prepare_c14_b4', 14, 4, 21)
     run_prepare(synth, 'prepare_c118_b2', 118, 2, 22)
     run_metrics('metrics_c14_s64', 64, 14, 20, 31)
+    run_augment(synth, 'augment_c14', 14, 4096, 41)
     os.makedirs(os.path.join(ROOT, 'tests', 'golden'), exist_ok=True)
     # name, case, batch, K, d, h, multi, seed, load_scale
     cases = [

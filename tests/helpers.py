@@ -10,9 +10,9 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 
 def golden_names():
-    """forward/backward goldens (prepare_* are goldens of the input producer, metrics_* of the evaluation metrics)"""
+    """forward/backward goldens (prepare_* are goldens of the input producer, metrics_* of the evaluation metrics, augment_* of the synthetic generator)"""
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, '*.npz')))
-    return [n for n in names if not n.startswith(('prepare_', 'metrics_'))]
+    return [n for n in names if not n.startswith(('prepare_', 'metrics_', 'augment_'))]
 
 
 def golden_depth(name):

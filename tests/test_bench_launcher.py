@@ -26,6 +26,25 @@ def test_bench_launches_its_own_ranks():
     assert out['n_gpus'] == 2 and out['sum_of_ranks'] == 3.0 and out['global_batch'] == 32768
 
 
+def test_bench_config5_rehearsal_names_its_workload():
+    """--config 5 = BASELINE configs[4] (case300, 8192 grids per GPU, K=10): the launcher path a future 8-GPU run of it takes."""
+    r = _run(['--config', '5', '--gpus', '2', '--steps', '2', '--warmup', '1', '--rehearse-cpu'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert out['n_gpus'] == 2 and out['config'] == 5 and out['global_batch'] == 2 * 8192 and 'case300' in out['workload']
+
+
+def test_bench_byte_and_flop_models_match_the_survey():
+    """compulsory bytes and nominal forward MFLOP per grid of the three bench configurations."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.bytes_per_grid(118) == 10504 and b.bytes_per_grid(300) == 23048 and b.bytes_per_grid(30) == 2284
+    assert abs(b.mflop_fwd_per_grid(118, 4) - 4.19216) < 1e-5 and abs(b.mflop_fwd_per_grid(300, 10) - 24.603) < 1e-3
+    assert abs(b.mflop_fwd_per_grid(30, 4) - 0.9828) < 1e-4
+
+
 def test_bench_rejects_a_world_size_that_does_not_match():
     r = _run(['--gpus', '4', '--rehearse-cpu'], env={'WORLD_SIZE': '2', 'RANK': '0', 'LOCAL_RANK': '0'})
     assert r.returncode != 0 and 'does not match' in (r.stderr + r.stdout)

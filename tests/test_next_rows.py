@@ -295,3 +295,57 @@ def test_default_topology_check_compares_the_whole_batch_and_inputs_are_version_
     bu.mul_(1.0)                                                 # in-place write bumps the version counter
     with pytest.raises(amd.GNSError):
         out[2].mean().backward()
+
+
+def _check_synth_against_augment_golden(device):
+    """the on-device synthetic generator against the REFERENCE'S OWN perturbation statements (GNS/augment_grids.py:
+    12-20, 30-53, compiled from the parsed file by oracle/make_goldens.run_augment and run 4096 times on the IEEE-14 base data):
+    ranges exact, the balance identity sum(Pd) == sum(Pg) of :51, means and spreads of every column statistically equal."""
+    import math
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'augment_c14.npz'))
+    n = 4096
+    assert int(g['n_draws']) == n
+    bu, li, ge = amd.synth.synth_grids(14, n, seed=77, device=device)
+    bu, li, ge = bu.double().cpu().numpy(), li.double().cpu().numpy(), ge.double().cpu().numpy()
+    mva = amd.synth.BASE_MVA
+    cols = {'r': li[:, :, 2], 'x': li[:, :, 3], 'b': li[:, :, 4], 'tau': li[:, :, 5], 'shift': li[:, :, 6] * 180.0 / math.pi,
+            'vg': ge[:, :, 4], 'pg': ge[:, :, 3] * mva, 'pd': bu[:, :, 2] * mva, 'qd': bu[:, :, 3] * mva}
+    eps = 2e-6
+    # multiplicative perturbations: value / base inside the reference's range, exact zeros where the base is zero
+    for k, rk, base in (('r', 'r_range', g['base_r']), ('x', 'x_range', g['base_x']), ('b', 'b_range', g['base_b']),
+                        ('vg', 'vg_range', g['base_vg']), ('qd', 'qd_range', g['base_qd'])):
+        lo, hi = g[rk]
+        nz = base != 0
+        ratio = cols[k][:, nz] / base[nz]
+        assert ratio.min() >= lo * (1 - eps) and ratio.max() <= hi * (1 + eps), (k, ratio.min(), ratio.max())
+        assert np.all(cols[k][:, ~nz] == 0)
+        assert ratio.min() < lo + 0.02 * (hi - lo) and ratio.max() > hi - 0.02 * (hi - lo)       # ... and the range is used
+    for k, rk in (('tau', 'tau_range'), ('shift', 'theta_shift_range')):
+        lo, hi = g[rk]
+        assert cols[k].min() >= lo - eps and cols[k].max() <= hi + eps and cols[k].min() < lo + 0.01 * (hi - lo)
+    span = g['base_pmax'] - g['base_pmin']
+    lo_pg, hi_pg = g['base_pmin'] + span * g['pg_range'][0], span * g['pg_range'][1]             # augment_grids.py:45-47
+    assert np.all(cols['pg'] >= lo_pg * (1 - eps) - eps) and np.all(cols['pg'] <= hi_pg * (1 + eps) + eps)
+    # the reference's draws obey the same bounds (the golden is the reference, not a restatement of it)
+    assert np.all(g['pg_min'] >= lo_pg - 1e-9) and np.all(g['pg_max'] <= hi_pg + 1e-9)
+    # balance (augment_grids.py:51): the reference reaches 1e-15 in float64, the fp32 generator 1e-5
+    assert float(g['balance_max_rel_err']) < 1e-12
+    assert np.abs(cols['pd'].sum(1) / cols['pg'].sum(1) - 1.0).max() < 1e-5
+    # every column: mean within 5 standard errors of the difference of two independent samples of n (138 comparisons: a 3-sigma
+    # bar would fail one of them by chance in every third data set; both samples are seeded, so the outcome is deterministic),
+    # spread within 6 %
+    for k in cols:
+        mu, sd = g[k + '_mean'], g[k + '_std']
+        se = np.sqrt(2.0) * sd / math.sqrt(n)
+        assert np.all(np.abs(cols[k].mean(0) - mu) <= 5.0 * se + 1e-6 * (1 + np.abs(mu))), (k, np.abs(cols[k].mean(0) - mu).max())
+        live = sd > 1e-12
+        assert np.all(np.abs(cols[k].std(0)[live] / sd[live] - 1.0) < 0.06), k
+
+
+def test_synthetic_grids_follow_the_reference_augmentation_statements():
+    _check_synth_against_augment_golden('cpu')
+
+
+@pytest.mark.gpu
+def test_synthetic_grids_follow_the_reference_augmentation_statements_on_the_device():
+    _check_synth_against_augment_golden('cuda')
