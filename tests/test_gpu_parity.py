@@ -610,7 +610,8 @@ def test_in_place_parameter_update_between_forward_and_backward_raises():
 @pytest.mark.parametrize('optim', ['Adam', 'SGD'])
 def test_reference_training_loop_runs_unchanged_on_a_cpu_resident_model(optim):
     """The literal loop of GNS/main.py:274-291 - model built on the CPU and never moved (main.py:227, the .to('cuda') at
-    :230-233 is commented out), CPU tensors from load_all_grids, per-grid keyword calls, torch.mean(torch.stack(losses)),
+    :230-233 is commented out), CPU tensors from load_all_grids, per-grid keyword calls, `losses[i % batch_size] = loss` into a
+    zeros tensor and torch.mean(losses) exactly as main.py:277-284 writes them,
     torch.optim.Adam(model.parameters()) - with only the import changed.  The kernels run on the GPU on a mirror of the
     parameters.  After two epochs the weights are compared with the same loop on the CPU oracle (torch autograd + the same
     optimiser), tolerance 1e-5 of max|w|:
@@ -632,12 +633,14 @@ def test_reference_training_loop_runs_unchanged_on_a_cpu_resident_model(optim):
     optimizer = mk(model.parameters())
     first_grad = None
     for epoch in range(epochs):
-        for batch in range(0, nr - bs + 1, bs):
-            losses, last_losses = [], []
+        for batch in range(0, nr, bs):
+            losses = torch.zeros(bs)                       # the reference's own collection: index assignment into a zeros tensor
+            last_losses = torch.zeros(bs)                  # (main.py:277-284), not a stacked list
             for i in range(batch, batch + bs):
                 v, theta, loss, last_loss = model(buses=bu[i], lines=li[i], generators=ge[i], B=B, L=L, G=G)
-                losses.append(loss); last_losses.append(last_loss)
-            total_loss = torch.mean(torch.stack(losses))
+                losses[i % bs] = loss
+                last_losses[i % bs] = last_loss.data
+            total_loss = torch.mean(losses)
             total_loss.backward()
             if first_grad is None:
                 first_grad = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
