@@ -235,27 +235,6 @@ __global__ void __launch_bounds__(GNS_BWDS_PHYS_THREADS) gns_bwds_phys_kernel(Gn
   }
 }
 
-// Pull [p, p + nfloats) into the scalar cache: one s_load_dword per 64-byte line, all in flight at once, one wait.  A sweep
-// workgroup starts on a cold scalar cache (every launch reverses another step = other weights) and a weight stream keeps only
-// two lines in flight, so without this the first bus of every workgroup pays a full L2 round trip per line.
-__device__ __forceinline__ void scalar_cache_warm(cfp p, long long nfloats) {
-#ifndef GNS_BWDS_NO_WARM
-  const unsigned nbytes = (unsigned)(nfloats * 4);
-  unsigned off, dummy;
-  asm volatile(
-      "s_mov_b32 %0, 0\n"
-      "1:\n"
-      "s_load_dword %1, %2, %0\n"
-      "s_add_u32 %0, %0, 64\n"
-      "s_cmp_lt_u32 %0, %3\n"
-      "s_cbranch_scc1 1b\n"
-      "s_waitcnt lgkmcnt(0)\n"
-      : "=&s"(off), "=&s"(dummy)
-      : "s"(p), "s"(nbytes)
-      : "scc", "memory");
-#endif
-}
-
 // ------------------------------------------------------------------------------------------------------------------------
 // One family (L_l and the phi net it reads) of the reverse update step, main.py:155-188 recomputed + reversed: the V2 sweep of
 // gns_backward.hip (see there for the window layout and the products that ride in spare rows / columns of a pass), as an

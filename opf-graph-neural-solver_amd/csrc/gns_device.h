@@ -190,6 +190,53 @@ __device__ __forceinline__ void stream_pairs(cfp p, F&& f, BG&& bg = BG{}, LK lk
 #endif
 }
 
+// Pull [p, p + nfloats) into the scalar cache: one s_load_dword per 64-byte line, all in flight at once, one wait.  Every step of
+// the K loop has its own weights, so whoever starts streaming a (family, step) block finds the scalar cache cold - and a weight
+// stream keeps only two lines in flight: without this the first bus of a sweep pays a full L2 round trip per line.
+__device__ __forceinline__ void scalar_cache_warm(cfp p, long long nfloats) {
+#ifndef GNS_NO_SCALAR_WARM
+  const unsigned nbytes = (unsigned)(nfloats * 4);
+  unsigned off, dummy;
+  asm volatile(
+      "s_mov_b32 %0, 0\n"
+      "1:\n"
+      "s_load_dword %1, %2, %0\n"
+      "s_add_u32 %0, %0, 64\n"
+      "s_cmp_lt_u32 %0, %3\n"
+      "s_cbranch_scc1 1b\n"
+      "s_waitcnt lgkmcnt(0)\n"
+      : "=&s"(off), "=&s"(dummy)
+      : "s"(p), "s"(nbytes)
+      : "scc", "memory");
+#endif
+}
+
+// The same in two halves, for a phase that has other work to do while the lines arrive: warm_issue puts the loads in flight and
+// hands back the registers they were issued with; they stay reserved until warm_wait (an s_waitcnt lgkmcnt(0)) has consumed them.
+struct WarmTok { unsigned off, dummy; };
+__device__ __forceinline__ WarmTok scalar_cache_warm_issue(cfp p, long long nfloats) {
+  WarmTok t{0u, 0u};
+#ifndef GNS_NO_SCALAR_WARM
+  const unsigned nbytes = (unsigned)(nfloats * 4);
+  asm volatile(
+      "s_mov_b32 %0, 0\n"
+      "1:\n"
+      "s_load_dword %1, %2, %0\n"
+      "s_add_u32 %0, %0, 64\n"
+      "s_cmp_lt_u32 %0, %3\n"
+      "s_cbranch_scc1 1b\n"
+      : "=&s"(t.off), "=&s"(t.dummy)
+      : "s"(p), "s"(nbytes)
+      : "scc", "memory");
+#endif
+  return t;
+}
+__device__ __forceinline__ void scalar_cache_warm_wait(WarmTok& t) {
+#ifndef GNS_NO_SCALAR_WARM
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(t.off), "+s"(t.dummy) : : "memory");
+#endif
+}
+
 // Pin a value to the point where it was computed.  MachineSink otherwise moves a whole LearningBlock's FMAs down
 // to the first use of its result (past the next line loop), keeping ~600 weights alive in v_writelane spills.
 __device__ __forceinline__ void pin(f2& v) { asm volatile("" : "+v"(v)); }

@@ -265,6 +265,8 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
     const int rs = A.save ? k : (k & 1), ws = A.save ? k + 1 : ((k + 1) & 1);
     FSTAMP(5)
     const long long koff = (long long)k;
+    // (warming the scalar cache with this step's weights here - gns_device.h, scalar_cache_warm - changes nothing: 0.841-0.846 ms
+    //  with, 0.843-0.845 ms without; sixteen waves hide the cold lines of a step's first units)
     // ================= phase U: latent / v / theta update (main.py:155-188) =================================
     // Work unit = (family, bus): family theta writes theta, family v writes v, family m writes the latent vector.
     // Units are dealt family-major so that a wave streams one family's weights (scalar-cache resident) and the 16

@@ -290,6 +290,19 @@ __global__ void __launch_bounds__(MAXT, MINW) gns_gw_forward_kernel(GnsGwFwdArgs
       }
       __syncthreads();
       // ================= BUS-2: delta_p / delta_q of step k, lambda, loss (main.py:45-57, 81-103, 198) ==============
+      // Every step has its own weights, and a wave streams each of them exactly once: the scalar cache is cold for all of them and
+      // a stream keeps two lines in flight.  One wave per workgroup puts the next step's L blocks (and the phi blocks of the step
+      // after) in flight here, all lines at once, while this phase - which streams nothing - does its sums.
+      WarmTok wt[6] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};
+      const bool warmer = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0 && k + 1 < K;     // (wave-uniform: the loads go through the scalar unit)
+      if (warmer) {
+#pragma unroll
+        for (int f = 0; f < 3; ++f) wt[f] = scalar_cache_warm_issue(PT + A.t_off[NPHI + f] + (koff + 1) * A.t_sz[NPHI + f], A.t_sz[NPHI + f]);
+        if (k + 2 < K) {
+#pragma unroll
+          for (int f = 0; f < NPHI; ++f) wt[3 + f] = scalar_cache_warm_issue(PT + A.t_off[f] + (koff + 2) * A.t_sz[f], A.t_sz[f]);
+        }
+      }
       if (bus_wave) {
         float sum_pf = 0.f, sum_qf = 0.f, sum_pt = 0.f, sum_qt = 0.f;
         for (int p = p0; p < p1; ++p) { const f4 t = phys[p]; sum_pf += t.x; sum_qf += t.y; }            // lines with dst == n
@@ -315,6 +328,10 @@ __global__ void __launch_bounds__(MAXT, MINW) gns_gw_forward_kernel(GnsGwFwdArgs
         const float sq = is_bus ? sdp * sdp + sdq * sdq : 0.f;
         tot_lane += A.gw[k] * sq;                                                // main.py:198 (mean over buses applied below)
         last_lane = sq;                                                          // main.py:199
+      }
+      if (warmer) {
+#pragma unroll
+        for (int f = 0; f < 6; ++f) scalar_cache_warm_wait(wt[f]);
       }
     }
 

@@ -312,6 +312,23 @@ __global__ void __launch_bounds__(MAXT, MINW) gns_gw_backward_kernel(GnsGwBwdArg
         constexpr int pf = MULTI ? 2 - decltype(r_)::value : 0;      // phi_m, phi_theta, phi_v | the single phi
         // after the last step nothing reads m_K: L_m.{K-1} / phi_m.{K-1} get no gradient (reference: .grad is None)
         const bool skip_round = MULTI && pf == 2 && k == K - 1;
+        // The weights of a (family, step) are streamed exactly once by every wave, so the scalar cache is cold for all of them and a
+        // stream keeps only two lines in flight: one wave of the workgroup pulls the round's four blocks (L' and phi', forward and
+        // data-gradient layouts, ~7 KB) in one burst (gns_device.h, scalar_cache_warm); its partners' streams then hit lines that
+        // are at least in flight.
+        if (!skip_round && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) {
+          constexpr int lw = MULTI ? (pf == 2 ? 2 : (pf == 1 ? 0 : 1)) : 0;          // the L net that reads this phi (single phi: L_theta first)
+          scalar_cache_warm(PT + A.t_off[NPHI + lw] + koff * A.t_sz[NPHI + lw], A.t_sz[NPHI + lw]);
+          scalar_cache_warm(PN + A.n_off[NPHI + lw] + koff * A.n_sz[NPHI + lw], A.n_sz[NPHI + lw]);
+          scalar_cache_warm(PT + A.t_off[pf] + koff * A.t_sz[pf], A.t_sz[pf]);
+          scalar_cache_warm(PN + A.n_off[pf] + koff * A.n_sz[pf], A.n_sz[pf]);
+          if constexpr (!MULTI) {                                                      // the single phi serves all three L nets in this one round
+            scalar_cache_warm(PT + A.t_off[NPHI + 1] + koff * A.t_sz[NPHI + 1], A.t_sz[NPHI + 1]);
+            scalar_cache_warm(PN + A.n_off[NPHI + 1] + koff * A.n_sz[NPHI + 1], A.n_sz[NPHI + 1]);
+            scalar_cache_warm(PT + A.t_off[NPHI + 2] + koff * A.t_sz[NPHI + 2], A.t_sz[NPHI + 2]);
+            scalar_cache_warm(PN + A.n_off[NPHI + 2] + koff * A.n_sz[NPHI + 2], A.n_sz[NPHI + 2]);
+          }
+        }
         if (bus_wave && !skip_round) {
           static_for<0, 3>([&](auto o_) {
             constexpr int l = (decltype(o_)::value == 0) ? 2 : decltype(o_)::value - 1;     // L_m first

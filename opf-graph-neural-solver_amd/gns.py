@@ -121,7 +121,7 @@ class _GNSFunction(torch.autograd.Function):
         _check(lib.gns_team_status_offset(ctypes.byref(cfg), Bt, int(need_grad), ctypes.byref(off)), 'gns_team_status_offset')
         uses_teams = off.value != ctypes.c_size_t(-1).value
         ctx.team_status = uses_teams and need_grad
-        if uses_teams and not need_grad:
+        if uses_teams and not need_grad and not torch.cuda.is_current_stream_capturing():
             mod.__dict__['_pending_status'] = (cfg, Bt, ws, dev)
         if need_grad:
             ctx.cfg, ctx.topo, ctx.ws, ctx.flat, ctx.Bt, ctx.bwd_bytes = cfg, topo, ws, flat, Bt, bwd_b.value
@@ -460,8 +460,8 @@ class GNS(nn.Module):
         return t[..., order]
 
     def forward(self, buses, lines, generators, B=None, L=None, G=None):
-        if self.__dict__.get('_pending_status') is not None:
-            self.check_status()
+        if self.__dict__.get('_pending_status') is not None and not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+            self.check_status()                             # (it synchronises: never inside a graph capture)
         params = self._ensure_flat()
         dev = params[0].device
         if dev.type != 'cuda':

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import torch
 import opf_graph_neural_solver_amd as amd
 lib = amd.load_library()
-for case, bt, d, K, mapping in ((14, 128, 10, 15, 0), (14, 128, 10, 15, 1), (14, 128, 20, 4, 0), (14, 1024, 10, 15, 0), (30, 128, 10, 15, 0)):
+for case, bt, d, K, mapping in ((14, 128, 10, 15, 0), (14, 128, 20, 4, 0), (14, 1024, 10, 15, 0), (118, 128, 20, 4, 0), (118, 1024, 20, 4, 0)):
     amd.set_option('train_mapping', mapping)
     torch.manual_seed(0)
     m = amd.GNS(d, 10, K, 0.9, True).cuda(); m.topology_check = 'first'
