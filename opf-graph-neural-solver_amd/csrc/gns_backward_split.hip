@@ -40,11 +40,13 @@ __global__ void __launch_bounds__(GNS_BWDS_PHYS_THREADS) gns_bwds_phys_kernel(Gn
             part = topo + topo[TH_PART] + pidx * (GNS_MAXP + 1), epart = topo + topo[TH_EPART] + pidx * (GNS_MAXP + 1);
   const int n0 = part[wave], n1 = part[wave + 1];
   const int e0 = epart[wave], e1 = epart[wave + 1];
-  const bool use_plane = A.use_plane != 0;
+  // LDS planes of the line phase: 2 = (v, theta) and the adjoint of delta_p of every bus, 1 = (v, theta) only (case300: 154 KB),
+  // 0 = none (the line phase gathers rows from L2 / HBM)
+  const bool use_plane = A.use_plane != 0, plane_dp = A.use_plane == 2;
   float* const red = lds;                                            // [W][64] partial sums of the lambda adjoint
-  float* const pl_v = lds + W * GNS_LANES;                           // three [N][64] planes (when they fit)
+  float* const pl_v = lds + W * GNS_LANES;                           // [N][64] planes (when they fit)
   float* const pl_th = pl_v + (use_plane ? N * GNS_LANES : 0);
-  float* const pl_dp = pl_th + (use_plane ? N * GNS_LANES : 0);
+  float* const pl_dp = pl_th + (plane_dp ? N * GNS_LANES : 0);
   const long long g = blockIdx.x;
   const long long R = gns_in_rows(N, E);
   const float* IN = A.in;
@@ -109,7 +111,8 @@ __global__ void __launch_bounds__(GNS_BWDS_PHYS_THREADS) gns_bwds_phys_kernel(Gn
         a.z = a.z + cdp * s1[j].z;
         a.w = 2.f * b1[j].w * s1[j].x;        // 2 Gs v for the gather, which then needs neither the state row nor the input row
         *row_ptr(A.adj, adj_row(n), lane) = a;
-        if (use_plane) { pl_v[n * GNS_LANES + lane] = s1[j].x; pl_th[n * GNS_LANES + lane] = s1[j].y; pl_dp[n * GNS_LANES + lane] = a.z; }
+        if (use_plane) { pl_v[n * GNS_LANES + lane] = s1[j].x; pl_th[n * GNS_LANES + lane] = s1[j].y; }
+        if (plane_dp) pl_dp[n * GNS_LANES + lane] = a.z;
         lb += a.z * (low2 ? 2.f * (b1[j].y - b1[j].x) : 2.f * (b1[j].z - b1[j].y));    // d Pg_new / d lambda  (main.py:53-57)
       }
     }
@@ -136,7 +139,8 @@ __global__ void __launch_bounds__(GNS_BWDS_PHYS_THREADS) gns_bwds_phys_kernel(Gn
         vt = pl_v[t * GNS_LANES + lane]; tht = pl_th[t * GNS_LANES + lane];
         tha = pl_th[ia * GNS_LANES + lane]; thb = pl_th[ib * GNS_LANES + lane];
         thc = pl_th[ic * GNS_LANES + lane]; thd = pl_th[id * GNS_LANES + lane];
-        Fb = pl_dp[t * GNS_LANES + lane]; Tb = pl_dp[s * GNS_LANES + lane];
+        if (plane_dp) { Fb = pl_dp[t * GNS_LANES + lane]; Tb = pl_dp[s * GNS_LANES + lane]; }
+        else { Fb = row_ptr(A.adj, adj_row(t), lane)->z; Tb = row_ptr(A.adj, adj_row(s), lane)->z; }
       } else {
         const f4 ss = *row_ptr(A.state, state_row(k + 1, s), lane), st = *row_ptr(A.state, state_row(k + 1, t), lane);
         vs = ss.x; ths = ss.y; vt = st.x; tht = st.y;
@@ -536,10 +540,10 @@ int gns_bwds_supported(int d, int h, int multi) {
 
 size_t gns_bwds_phys_lds(int N, int* use_plane) {
   const size_t red = (size_t)GNS_BWDS_PHYS_WAVES * GNS_LANES * 4;
-  const size_t planes = 3 * (size_t)N * GNS_LANES * 4;
-  const bool fits = red + planes <= (size_t)160 * 1024;
-  if (use_plane) *use_plane = fits ? 1 : 0;
-  return fits ? red + planes : red;
+  const size_t plane = (size_t)N * GNS_LANES * 4;
+  const int level = red + 3 * plane <= (size_t)160 * 1024 ? 2 : (red + 2 * plane <= (size_t)160 * 1024 ? 1 : 0);
+  if (use_plane) *use_plane = level;
+  return red + (level == 2 ? 3 : (level == 1 ? 2 : 0)) * plane;
 }
 
 int gns_launch_bwds_phys(const GnsBwdsArgs& A, size_t lds, hipStream_t st) {

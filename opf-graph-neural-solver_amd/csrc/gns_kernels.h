@@ -96,7 +96,7 @@ struct GnsBwdsArgs {
   int N, E, K, k;
   int C, part_idx, R;      // sweep: bus chunks per group, their partition table, groups per workgroup
   int RB, RBA;             // state rows per bus (1 + mq), adjoint rows per bus (4 + 6 mq)
-  int use_plane;           // phys: (v, theta, dpbar) of all buses in three LDS planes
+  int use_plane;           // phys: LDS planes of the line phase: 2 (v, theta, dpbar) of all buses, 1 (v, theta) only, 0 none
   int mode;                // sweep kernels per step: 0 {m}{theta}{v}, 1 {m}{theta+v}, 2 {m+theta+v} (gns_backward_split.hip)
 };
 int gns_bwds_supported(int d, int h, int multi);

@@ -181,7 +181,10 @@ class GraphedStep:
     state, so N replays equal N eager steps bit for bit.  ``run`` returns (mean total_loss, mean last_loss) as tensors that the
     NEXT replay overwrites."""
 
-    def __init__(self, model, optimizer, buses, lines, generators):
+    def __init__(self, model, optimizer, buses, lines, generators, copy_inputs=True):
+        """``copy_inputs=False``: capture on the given tensors themselves instead of private copies - for a resident batch that is
+        trained on repeatedly or refilled in place (a batch that is a slice of a data set bound with ``GNS.bind_dataset`` then keeps
+        reading the set's packed copy: no input packing kernel in the graph)."""
         if not isinstance(optimizer, FlatOptimizer) or not optimizer._use_native:
             raise ValueError('GraphedStep needs a FlatOptimizer running the library Adam (training.make_optimizer on a GPU model)')
         if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
@@ -191,7 +194,12 @@ class GraphedStep:
             raise ValueError('GraphedStep needs a GPU-resident model')
         dev = flat.device
         self.model, self.optimizer = model, optimizer
-        self.static = tuple(t.detach().to(dev).contiguous().clone() for t in (buses, lines, generators))
+        if copy_inputs:
+            self.static = tuple(t.detach().to(dev).contiguous().clone() for t in (buses, lines, generators))
+        else:
+            if not all(t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 for t in (buses, lines, generators)):
+                raise ValueError('GraphedStep(copy_inputs=False) needs contiguous float32 device tensors')
+            self.static = (buses, lines, generators)
         B, L, G = get_BLG()
         optimizer.capturable = True
         # the id columns are validated on the warm-up call; replays trust them like ``topology_check = 'first'`` does (a host

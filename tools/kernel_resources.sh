@@ -4,11 +4,11 @@
 cd "$(dirname "$0")/../opf-graph-neural-solver_amd/csrc"
 F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -ffp-contract=off -Wno-unused-function"
 echo "# hipcc -Rpass-analysis=kernel-resource-usage, gfx950, shipped sources (per instantiation)"
-for f in gns_forward gns_backward gns_gridwg gns_gridwg_bwd gns_api; do
+for f in gns_forward gns_backward gns_backward_split gns_gridwg gns_gridwg_bwd gns_api; do
   [ -n "$KR_REUSE" ] || hipcc $F -Rpass-analysis=kernel-resource-usage -c $f.hip -o /tmp/kr_$f.o 2> /tmp/kr_$f.txt &
 done
 wait
-for f in gns_forward gns_backward gns_gridwg gns_gridwg_bwd gns_api; do
+for f in gns_forward gns_backward gns_backward_split gns_gridwg gns_gridwg_bwd gns_api; do
   python3 - /tmp/kr_$f.txt <<'PY'
 import re, subprocess, sys
 cur = None; rows = {}
