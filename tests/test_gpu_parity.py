@@ -1031,3 +1031,39 @@ def test_a_team_that_gave_up_is_reported_to_the_host_before_any_gradient_is_comp
     with torch.no_grad():
         m(bu, li, ge)
     assert m.__dict__.get('_pending_status') is None
+
+
+@pytest.mark.parametrize('case,bt,d,K', [(118, 130, 20, 4), (30, 40000, 20, 3), (14, 70000, 10, 2), (300, 70, 20, 5)])
+def test_split_backward_modes_agree_with_the_persistent_kernel(case, bt, d, K, lane_mapping):
+    """The split backward (bwd_variant 4) in its three sweep modes against the persistent kernel (variant 2) on batches the goldens do
+    not reach: ragged (130, 70 grids), many groups per sweep workgroup (40 000 / 70 000 grids = 625 / 1 094 groups: the accumulator
+    tiles are carried across the groups of a workgroup, R = 2 / 4), both compiled model widths, non-trivial upstream gradients.
+    Same arithmetic, other summation orders: gradients to 5e-6 of max|grad|; each mode bitwise reproducible."""
+    import opf_graph_neural_solver_amd as amd
+    torch.manual_seed(7)
+    m = amd.GNS(d, 10, K, 0.9, True).cuda()
+    m.topology_check = 'first'
+    bu, li, ge = amd.synth.synth_grids(case, bt, seed=13, device='cuda')
+    gen = torch.Generator(device='cuda').manual_seed(1)
+    wt, wl = torch.rand(bt, device='cuda', generator=gen), torch.rand(bt, device='cuda', generator=gen)
+    wv = torch.randn(bt, bu.shape[1], device='cuda', generator=gen) * 1e-3
+
+    def grads():
+        m.zero_grad()
+        v, th, tot, last = m(bu, li, ge)
+        ((tot * wt).sum() / bt + (last * wl).mean() + (v * wv).sum() + (th * wv).sum() * 0.5).backward()
+        return torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
+
+    old = amd.get_option('bwd_variant'), amd.get_option('bwds_mode')
+    try:
+        amd.set_option('bwd_variant', 2)
+        ref = grads()
+        scale = float(ref.abs().max())
+        for mode in (1, 0, 2):
+            amd.set_option('bwd_variant', 4); amd.set_option('bwds_mode', mode)
+            g1, g2 = grads(), grads()
+            assert torch.equal(g1, g2), f'mode {mode} is not run-to-run reproducible'
+            err = float((g1 - ref).abs().max()) / scale
+            assert err < 5e-6, f'mode {mode}: {err:.2e} of max|grad|'
+    finally:
+        amd.set_option('bwd_variant', old[0]); amd.set_option('bwds_mode', old[1])
