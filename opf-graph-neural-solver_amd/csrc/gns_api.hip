@@ -495,7 +495,7 @@ extern "C" int gns_backward(const gns_config* cfg, const void* topo_dev, const f
     A.Bt = Bt; A.G = S.groups; A.slab_floats = S.slab_floats; A.N = N; A.E = E; A.K = K;
     A.C = S.C; A.part_idx = gns_part_index(S.C); A.R = S.R;
     A.RB = (int)(1 + S.mq); A.RBA = (int)S.adj_rows;
-    A.mode = tuning().bwds_mode;
+    A.mode = cfg->multiple_phi ? tuning().bwds_mode : 2;          // the single phi is reversed after all three L nets: bus-major
     const size_t lds = gns_bwds_phys_lds(N, &A.use_plane);
     prof_mark(1, true, st);
     for (int k = K - 1; k >= 0; --k) {
@@ -503,7 +503,7 @@ extern "C" int gns_backward(const gns_config* cfg, const void* topo_dev, const f
       A.gwk = (float)std::pow((double)cfg->gamma, (double)(K - k));
       rc = gns_launch_bwds_phys(A, lds, st);
       if (rc != GNS_OK) return rc;
-      rc = gns_launch_bwds_sweep(d, h, A, st);
+      rc = gns_launch_bwds_sweep(d, h, cfg->multiple_phi, A, st);
       if (rc != GNS_OK) return rc;
     }
     prof_mark(1, false, st);

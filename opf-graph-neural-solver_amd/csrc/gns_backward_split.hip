@@ -240,22 +240,19 @@ __global__ void __launch_bounds__(GNS_BWDS_PHYS_THREADS) gns_bwds_phys_kernel(Gn
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// One family (L_l and the phi net it reads) of the reverse update step, main.py:155-188 recomputed + reversed: the V2 sweep of
-// gns_backward.hip (see there for the window layout and the products that ride in spare rows / columns of a pass), as an
-// object - its weight-gradient tiles and weight-stream heads - so that a workgroup can run one, two or all three families of a
-// bus back to back on the rows it has loaded once.
-template <int D, int H, int l>
-struct BwdsFam {
-  using C = GnsDims<D, H, true>;
-  static constexpr int fphi = l == 0 ? 1 : (l == 1 ? 0 : 2);
-  static constexpr int OUT = (l == 2) ? D : 1, OUTP = OUT + (OUT & 1);
+// The reverse update step of one bus, main.py:155-188 recomputed + reversed, in two objects: BwdsL = one bus net L_l (recompute, layer-wise
+// backward, input adjoints), BwdsPhi = one phi net over the lines ending at the bus (head / tail recompute, backward, latent adjoint).
+// Each holds its weight-gradient tiles and weight-stream heads, so that a workgroup can run one, two or all three families of a bus back
+// to back on the rows it has loaded once.  The code is the V2 sweep of gns_backward.hip (see there for the window layout and the
+// products that ride in spare rows / columns of a pass).  MULTI: every L net reads its own phi (main.py:157-167); single phi: the three
+// L nets read the one hidden sum and its adjoint is their sum (main.py:169-171).
+template <int D, int H, bool MULTI>
+struct BwdsShape {
+  using C = GnsDims<D, H, MULTI>;
   static constexpr int LIN = C::LF_IN, XL = (LIN + 1) / 2, PIN = C::PHI_IN, SOFF = 2 + D / 2;
-  static constexpr int NB1 = (2 * XL + 15) / 16, NA4 = (OUTP + 11) / 12, NDM = (D + 15) / 16;
-  using NL = NLay<LIN, H, OUTP>;
+  static constexpr int NB1 = (2 * XL + 15) / 16, NDM = (D + 15) / 16;
   static constexpr bool WIDE = D > 16;
   using SW = std::conditional_t<WIDE, GwSubWide, GwSub>;
-  static constexpr bool FOLD4 = WIDE && l < 2 && (2 * XL - 16 * (NB1 - 1)) + H + 1 <= 16;   // [x tail | a2 | 1] fits one window
-  static constexpr bool FOLDM = GwSubWide::NA >= 16 && WIDE && l == 2 && (2 * XL - 16 * (NB1 - 1)) + H + 1 <= 16 && H + (OUT - 16) <= 16;
   static constexpr int XT = 2 * XL - 16 * (NB1 - 1);                                          // x columns of the last dW1 window
   static constexpr int W2OFF = WIDE ? 16 - XT : 0;                                            // its first B column
   static constexpr int NDMF = WIDE ? 1 : NDM;                                                 // latent tiles left after the fold
@@ -263,137 +260,106 @@ struct BwdsFam {
   using L0 = WLink<false, true>;            // first of a group of linked weight streams (gns_device.h)
   using L1 = WLink<true, true>;             // middle
   using L2 = WLink<true, false>;            // last
+};
 
-  f32x4 T1[NB1], T2, T4[NA4], TP1, TP2, TPm[NDM];
-  cfp nb, pnb, ptb, ptl;
+template <int D, int H, bool MULTI, int l>
+struct BwdsL : BwdsShape<D, H, MULTI> {
+  using B = BwdsShape<D, H, MULTI>;
+  using C = typename B::C;
+  using SW = typename B::SW;
+  using L0 = typename B::L0; using L1 = typename B::L1; using L2 = typename B::L2;
+  static constexpr int LIN = B::LIN, XL = B::XL, SOFF = B::SOFF, NB1 = B::NB1, XT = B::XT, W2OFF = B::W2OFF;
+  static constexpr bool WIDE = B::WIDE;
+  static constexpr int fphi = MULTI ? (l == 0 ? 1 : (l == 1 ? 0 : 2)) : 0;
+  static constexpr int OUT = (l == 2) ? D : 1, OUTP = OUT + (OUT & 1), NA4 = (OUTP + 11) / 12;
+  using NL = NLay<LIN, H, OUTP>;
+  static constexpr bool FOLD4 = WIDE && l < 2 && XT + H + 1 <= 16;                           // [x tail | a2 | 1] fits one window
+  static constexpr bool FOLDM = GwSubWide::NA >= 16 && WIDE && l == 2 && XT + H + 1 <= 16 && H + (OUT - 16) <= 16;
+
+  f32x4 T1[NB1], T2, T4[NA4];
+  cfp nb, ptl;
 
   __device__ __forceinline__ void init(const GnsBwdsArgs& A) {
     const long long koff = A.k;
     nb = (cfp)A.pn + A.n_off[C::NPHI + l] + koff * A.n_sz[C::NPHI + l];
-    pnb = (cfp)A.pn + A.n_off[fphi] + koff * A.n_sz[fphi];
-    ptb = (cfp)A.pt + A.t_off[fphi] + koff * A.t_sz[fphi];
     ptl = (cfp)A.pt + A.t_off[C::NPHI + l] + koff * A.t_sz[C::NPHI + l];
     scalar_cache_warm(ptl, A.t_sz[C::NPHI + l]); scalar_cache_warm(nb, A.n_sz[C::NPHI + l]);
-    scalar_cache_warm(ptb, A.t_sz[fphi]); scalar_cache_warm(pnb, A.n_sz[fphi]);
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < NB1; ++t) T1[t] = z4;
 #pragma unroll
     for (int t = 0; t < NA4; ++t) T4[t] = z4;
-#pragma unroll
-    for (int t = 0; t < NDM; ++t) TPm[t] = z4;
-    T2 = z4; TP1 = z4; TP2 = z4;
+    T2 = z4;
   }
 
-  // One bus of one 64-grid group.  xs = [v theta | dp dq | m | (the family's hidden sum goes here) | deg, 1]; g3s = the upstream
-  // of the scalar output (L_theta: thbar, L_v: vbar or 0 on a generator bus); L_m takes macc = d/dm_{k+1} as its upstream.
-  // xsum (d/dv, d/dtheta, d/ddp of the L inputs) and macc (d/dm) accumulate.
+  // xs = [v theta | dp dq | m | (the hidden sum this net reads goes here) | deg, 1]; g3s = the upstream of the scalar output (L_theta:
+  // thbar, L_v: vbar or 0 on a generator bus); L_m takes macc = d/dm_{k+1} as its upstream.  xsum (d/dv, d/dtheta, d/ddp of the L
+  // inputs) and macc (d/dm) accumulate; gS = the adjoint of the hidden sum: assigned (ACC_GS false) or accumulated (the single phi).
+  template <bool ACC_GS>
   __device__ __forceinline__ void bus(const GnsBwdsArgs& A, float* rec, int lane, long long g, int n, float g3s, f2 (&xs)[XL],
-                                      f2 (&macc)[D / 2], f4& xsum, int p0, int p1, long long row_ein) {
-    const float* IN = A.in;
-    f2 (&m)[D / 2] = reinterpret_cast<f2 (&)[D / 2]>(xs[2]);
+                                      f2 (&macc)[D / 2], f4& xsum, f2 (&gS)[H / 2]) {
     f2 (&S)[H / 2] = reinterpret_cast<f2 (&)[H / 2]>(xs[SOFF]);
     load_pairs<H>(A.msg, ((((long long)A.k * A.G + g) * A.N + n) * C::NPHI + fphi) * C::HQ, lane, S);
     WFirst wf;
-    f2 gS[H / 2];                                       // adjoint of the hidden-vector sum: what every line ending at n receives
-    {
-      f2 a1[H / 2], a2[H / 2], g2[H / 2], g1[H / 2];
-      mlp2_fwd<LIN, H>(ptl, xs, a1, a2, NoBG{}, L0{nullptr, nb, &wf});
-      // output layer: g2 = (W4^T g3) * lrelu'(a2);  dW4 | db4 += g3 (x) [a2 | 1]
-      if constexpr (l == 2) {
-        bwd_rows<OUTP, H>(nb, macc, g2, NoBG{}, L2{&wf, nullptr, nullptr});       // m += L_m (main.py:188); a pass follows
-      } else {
-        const f2 g3v[1] = {f2{g3s, 0.f}};                                           // theta += L_theta (:182); v only without a generator (:184-186)
-        bwd_rows<2, H>(nb, g3v, g2, NoBG{}, std::conditional_t<FOLD4, L1, L2>{&wf, nb + NL::oW2, &wf});
-      }
+    f2 a1[H / 2], a2[H / 2], g2[H / 2], g1[H / 2];
+    mlp2_fwd<LIN, H>(ptl, xs, a1, a2, NoBG{}, L0{nullptr, nb, &wf});
+    // output layer: g2 = (W4^T g3) * lrelu'(a2);  dW4 | db4 += g3 (x) [a2 | 1]
+    if constexpr (l == 2) {
+      bwd_rows<OUTP, H>(nb, macc, g2, NoBG{}, L2{&wf, nullptr, nullptr});       // m += L_m (main.py:188); a pass follows
+    } else {
+      const f2 g3v[1] = {f2{g3s, 0.f}};                                           // theta += L_theta (:182); v only without a generator (:184-186)
+      bwd_rows<2, H>(nb, g3v, g2, NoBG{}, std::conditional_t<FOLD4, L1, L2>{&wf, nb + NL::oW2, &wf});
+    }
 #pragma unroll
-      for (int u = 0; u < H / 2; ++u) g2[u] = g2[u] * dlrelu2(a2[u]);
-      if constexpr (FOLD4 || FOLDM) {                   // parked at columns 16..26 until the last dW1 window contracts them
-        static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putB<SW>(rec, lane, 8 + j, a2[j]); });
-        gws_putB<SW>(rec, lane, 8 + H / 2, f2{1.f, 0.f});
-        if constexpr (FOLDM) {
-          static_for<0, 8>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA<SW>(rec, lane, j, macc[j]); });
-          gws_w2r(); gws_pass<SW, 16>(rec, lane, T4[0]); gws_r2w();
-        }
-      } else {
-        static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putB<SW>(rec, lane, j, a2[j]); });
-        gws_putB<SW>(rec, lane, H / 2, f2{1.f, 0.f});
-        static_for<0, NA4>([&](auto t_) {
-          constexpr int t = decltype(t_)::value;
-          if constexpr (l == 2) {
-            static_for<0, 6>([&](auto j_) { constexpr int j = decltype(j_)::value; if constexpr (6 * t + j < D / 2) gws_putA<SW>(rec, lane, j, macc[6 * t + j]); });
-          } else {
-            gws_putA<SW>(rec, lane, 0, f2{g3s, 0.f});
-          }
-          gws_w2r(); gws_pass<SW>(rec, lane, T4[t]); gws_r2w();
-        });
+    for (int u = 0; u < H / 2; ++u) g2[u] = g2[u] * dlrelu2(a2[u]);
+    if constexpr (FOLD4 || FOLDM) {                   // parked at columns 16..26 until the last dW1 window contracts them
+      static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putB<SW>(rec, lane, 8 + j, a2[j]); });
+      gws_putB<SW>(rec, lane, 8 + H / 2, f2{1.f, 0.f});
+      if constexpr (FOLDM) {
+        static_for<0, 8>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA<SW>(rec, lane, j, macc[j]); });
+        gws_w2r(); gws_pass<SW, 16>(rec, lane, T4[0]); gws_r2w();
       }
-      // hidden layer: g1 = (W2^T g2) * lrelu'(a1);  dW2 | db2 += g2 (x) [a1 | 1]
-      bwd_rows<H, H>(nb + NL::oW2, g2, g1, NoBG{}, std::conditional_t<FOLD4, L2, NoLink>{&wf, nullptr, nullptr});
-#pragma unroll
-      for (int u = 0; u < H / 2; ++u) g1[u] = g1[u] * dlrelu2(a1[u]);
-      static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA<SW>(rec, lane, j, g2[j]); gws_putB<SW>(rec, lane, j, a1[j]); });
+    } else {
+      static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putB<SW>(rec, lane, j, a2[j]); });
       gws_putB<SW>(rec, lane, H / 2, f2{1.f, 0.f});
-      gws_w2r(); gws_pass<SW>(rec, lane, T2); gws_r2w();
-      // first layer: dW1 | db1 += g1 (x) [x | 1] in 16-column windows
-      static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA<SW>(rec, lane, j, g1[j]); });
-      if constexpr (FOLD4) gws_putA<SW>(rec, lane, H / 2, f2{g3s, 0.f});            // row 10: g3
-      if constexpr (FOLDM) static_for<0, (OUT - 16) / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA<SW>(rec, lane, H / 2 + j, macc[8 + j]); });   // rows 10..: upstream of outputs 16..d-1 (macc is still mbar_{k+1} here)
-      static_for<0, NB1>([&](auto t_) {
+      static_for<0, NA4>([&](auto t_) {
         constexpr int t = decltype(t_)::value;
-        constexpr int po = (WIDE && t == NB1 - 1) ? W2OFF / 2 : 0;                   // the last window sits right below column 16
-        static_for<0, 8>([&](auto j_) { constexpr int j = decltype(j_)::value; if constexpr (8 * t + j < XL) gws_putB<SW>(rec, lane, po + j, xs[8 * t + j]); });
-        gws_w2r(); gws_pass<SW, (WIDE && t == NB1 - 1) ? W2OFF : 0>(rec, lane, T1[t]); gws_r2w();
-      });
-      // input adjoints, four at a time, straight to their consumers
-      bwd_inputs<(LIN + 3) / 4, H>(nb + NL::total, g1, [&](auto ip_, f2 v) {
-        constexpr int ip = decltype(ip_)::value;
-        if constexpr (ip == 0) { xsum.x += v.x; xsum.y += v.y; }
-        else if constexpr (ip == 1) xsum.z += v.x;
-        else if constexpr (ip < SOFF) macc[ip - 2] += v;
-        else if constexpr (ip < SOFF + H / 2) gS[ip - SOFF] = v;
+        if constexpr (l == 2) {
+          static_for<0, 6>([&](auto j_) { constexpr int j = decltype(j_)::value; if constexpr (6 * t + j < D / 2) gws_putA<SW>(rec, lane, j, macc[6 * t + j]); });
+        } else {
+          gws_putA<SW>(rec, lane, 0, f2{g3s, 0.f});
+        }
+        gws_w2r(); gws_pass<SW>(rec, lane, T4[t]); gws_r2w();
       });
     }
-    if (p0 < p1) {                                      // back through the hidden vectors of the lines ending at n
-      f2 uh[H / 2], G1[H / 2];
-      if constexpr (WIDE)                               // the latent tail, parked behind [line parameters | 1] at columns 16..21
-        static_for<0, (D - 16) / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putB<SW>(rec, lane, 8 + (PIN - D + 2) / 2 + j, m[8 + j]); });
-      phi_head<D, H>(ptb, m, uh);
+    // hidden layer: g1 = (W2^T g2) * lrelu'(a1);  dW2 | db2 += g2 (x) [a1 | 1]
+    bwd_rows<H, H>(nb + NL::oW2, g2, g1, NoBG{}, std::conditional_t<FOLD4, L2, NoLink>{&wf, nullptr, nullptr});
 #pragma unroll
-      for (int j = 0; j < H / 2; ++j) G1[j] = f2{0.f, 0.f};
-      for (int p = p0; p < p1; ++p) {
-        const f4 ea = *row_ptr(IN, row_ein + 3LL * p, lane), eb = *row_ptr(IN, row_ein + 3LL * p + 1, lane);
-        const f2 xt[3] = {f2{ea.x, ea.y}, f2{ea.z, ea.w}, f2{eb.x, 0.f}};
-        f2 a1[H / 2], a2[H / 2], g2[H / 2], g1[H / 2];
-        phi_tail<PIN, H, D>(ptb, uh, xt, a1, a2, NoBG{}, L0{nullptr, pnb, &wf});
-#pragma unroll
-        for (int u = 0; u < H / 2; ++u) g2[u] = gS[u] * dlrelu2(a2[u]);
-        bwd_rows<H, H>(pnb, g2, g1, NoBG{}, L2{&wf, nullptr, nullptr});
-#pragma unroll
-        for (int u = 0; u < H / 2; ++u) { g1[u] = g1[u] * dlrelu2(a1[u]); G1[u] += g1[u]; }
-        constexpr int pw = WIDE ? 8 : 0;                // wide window: the line's pass contracts columns 16..31
-        static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA<SW>(rec, lane, j, g1[j]); });
-        gws_putB<SW>(rec, lane, pw + 0, xt[0]); gws_putB<SW>(rec, lane, pw + 1, xt[1]); gws_putB<SW>(rec, lane, pw + 2, f2{xt[2].x, 1.f});
-        gws_w2r(); gws_pass<SW, 2 * pw>(rec, lane, TP1); gws_r2w();
-        static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA<SW>(rec, lane, j, g2[j]); gws_putB<SW>(rec, lane, j, a1[j]); });
-        gws_putB<SW>(rec, lane, H / 2, f2{1.f, 0.f});
-        gws_w2r(); gws_pass<SW>(rec, lane, TP2); gws_r2w();
-      }
-      // x = [m(dst) | ...] (main.py:155): d/dm += W1[:, :d]^T G1 and the latent columns of dW1 += G1 (x) m, once per bus
-      bwd_inputs<(D + 3) / 4, H>(pnb + NLay2<PIN, H>::total, G1, [&](auto ip_, f2 v) {
-        constexpr int ip = decltype(ip_)::value;
-        if constexpr (ip < D / 2) macc[ip] += v;
-      });
-      static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA<SW>(rec, lane, j, G1[j]); });
-      static_for<0, NDMF>([&](auto t_) {
-        constexpr int t = decltype(t_)::value;
-        static_for<0, 8>([&](auto j_) { constexpr int j = decltype(j_)::value; if constexpr (8 * t + j < D / 2) gws_putB<SW>(rec, lane, j, m[8 * t + j]); });
-        gws_w2r(); gws_pass<SW>(rec, lane, TPm[t]); gws_r2w();
-      });
-    }
+    for (int u = 0; u < H / 2; ++u) g1[u] = g1[u] * dlrelu2(a1[u]);
+    static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA<SW>(rec, lane, j, g2[j]); gws_putB<SW>(rec, lane, j, a1[j]); });
+    gws_putB<SW>(rec, lane, H / 2, f2{1.f, 0.f});
+    gws_w2r(); gws_pass<SW>(rec, lane, T2); gws_r2w();
+    // first layer: dW1 | db1 += g1 (x) [x | 1] in 16-column windows
+    static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA<SW>(rec, lane, j, g1[j]); });
+    if constexpr (FOLD4) gws_putA<SW>(rec, lane, H / 2, f2{g3s, 0.f});            // row 10: g3
+    if constexpr (FOLDM) static_for<0, (OUT - 16) / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA<SW>(rec, lane, H / 2 + j, macc[8 + j]); });   // rows 10..: upstream of outputs 16..d-1 (macc is still mbar_{k+1} here)
+    static_for<0, NB1>([&](auto t_) {
+      constexpr int t = decltype(t_)::value;
+      constexpr int po = (WIDE && t == NB1 - 1) ? W2OFF / 2 : 0;                   // the last window sits right below column 16
+      static_for<0, 8>([&](auto j_) { constexpr int j = decltype(j_)::value; if constexpr (8 * t + j < XL) gws_putB<SW>(rec, lane, po + j, xs[8 * t + j]); });
+      gws_w2r(); gws_pass<SW, (WIDE && t == NB1 - 1) ? W2OFF : 0>(rec, lane, T1[t]); gws_r2w();
+    });
+    // input adjoints, four at a time, straight to their consumers
+    bwd_inputs<(LIN + 3) / 4, H>(nb + NL::total, g1, [&](auto ip_, f2 v) {
+      constexpr int ip = decltype(ip_)::value;
+      if constexpr (ip == 0) { xsum.x += v.x; xsum.y += v.y; }
+      else if constexpr (ip == 1) xsum.z += v.x;
+      else if constexpr (ip < SOFF) macc[ip - 2] += v;
+      else if constexpr (ip < SOFF + H / 2) { if constexpr (ACC_GS) gS[ip - SOFF] += v; else gS[ip - SOFF] = v; }
+    });
   }
 
-  // the family's tiles -> the (family, step) blocks of the workgroup's slab (folded blocks: W1[H][IN] b1 W2 b2 [W4 b4]); plain stores
+  // the tiles -> the (family, step) block of the workgroup's slab (folded block: W1[H][IN] b1 W2 b2 W4 b4); plain stores
   __device__ __forceinline__ void flush(const GnsBwdsArgs& A, int lane, float* slab) {
     const long long koff = A.k;
     constexpr int ob1 = LIN * H, oW2 = ob1 + H, ob2 = oW2 + H * H, oW4 = ob2 + H, ob4 = oW4 + OUT * H;
@@ -412,8 +378,81 @@ struct BwdsFam {
     else if constexpr (!FOLD4)
     static_for<0, NA4>([&](auto t_) { constexpr int t = decltype(t_)::value;
       gws_flush(lane, T4[t], lb_, [&](int c, int il) { const int j = 12 * t + c; return (c < 12 && j < OUT) ? (il < H ? oW4 + j * H + il : (il == H ? ob4 + j : -1)) : -1; }, true); });
+  }
+};
+
+template <int D, int H, bool MULTI, int PF>
+struct BwdsPhi : BwdsShape<D, H, MULTI> {
+  using B = BwdsShape<D, H, MULTI>;
+  using C = typename B::C;
+  using SW = typename B::SW;
+  using L0 = typename B::L0; using L2 = typename B::L2;
+  static constexpr int XL = B::XL, PIN = B::PIN, NDM = B::NDM, NDMF = B::NDMF;
+  static constexpr bool WIDE = B::WIDE;
+
+  f32x4 TP1, TP2, TPm[NDM];
+  cfp pnb, ptb;
+
+  __device__ __forceinline__ void init(const GnsBwdsArgs& A) {
+    const long long koff = A.k;
+    pnb = (cfp)A.pn + A.n_off[PF] + koff * A.n_sz[PF];
+    ptb = (cfp)A.pt + A.t_off[PF] + koff * A.t_sz[PF];
+    scalar_cache_warm(ptb, A.t_sz[PF]); scalar_cache_warm(pnb, A.n_sz[PF]);
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NDM; ++t) TPm[t] = z4;
+    TP1 = z4; TP2 = z4;
+  }
+
+  // back through the hidden vectors of the lines p0..p1 ending at the bus: gS = the adjoint of their sum
+  __device__ __forceinline__ void bus(const GnsBwdsArgs& A, float* rec, int lane, const f2 (&xs)[XL], const f2 (&gS)[H / 2],
+                                      f2 (&macc)[D / 2], int p0, int p1, long long row_ein) {
+    if (p0 >= p1) return;
+    const float* IN = A.in;
+    const f2 (&m)[D / 2] = reinterpret_cast<const f2 (&)[D / 2]>(xs[2]);
+    WFirst wf;
+    f2 uh[H / 2], G1[H / 2];
+    if constexpr (WIDE)                               // the latent tail, parked behind [line parameters | 1] at columns 16..21
+      static_for<0, (D - 16) / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putB<SW>(rec, lane, 8 + (PIN - D + 2) / 2 + j, m[8 + j]); });
+    phi_head<D, H>(ptb, m, uh);
+#pragma unroll
+    for (int j = 0; j < H / 2; ++j) G1[j] = f2{0.f, 0.f};
+    for (int p = p0; p < p1; ++p) {
+      const f4 ea = *row_ptr(IN, row_ein + 3LL * p, lane), eb = *row_ptr(IN, row_ein + 3LL * p + 1, lane);
+      const f2 xt[3] = {f2{ea.x, ea.y}, f2{ea.z, ea.w}, f2{eb.x, 0.f}};
+      f2 a1[H / 2], a2[H / 2], g2[H / 2], g1[H / 2];
+      phi_tail<PIN, H, D>(ptb, uh, xt, a1, a2, NoBG{}, L0{nullptr, pnb, &wf});
+#pragma unroll
+      for (int u = 0; u < H / 2; ++u) g2[u] = gS[u] * dlrelu2(a2[u]);
+      bwd_rows<H, H>(pnb, g2, g1, NoBG{}, L2{&wf, nullptr, nullptr});
+#pragma unroll
+      for (int u = 0; u < H / 2; ++u) { g1[u] = g1[u] * dlrelu2(a1[u]); G1[u] += g1[u]; }
+      constexpr int pw = WIDE ? 8 : 0;                // wide window: the line's pass contracts columns 16..31
+      static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA<SW>(rec, lane, j, g1[j]); });
+      gws_putB<SW>(rec, lane, pw + 0, xt[0]); gws_putB<SW>(rec, lane, pw + 1, xt[1]); gws_putB<SW>(rec, lane, pw + 2, f2{xt[2].x, 1.f});
+      gws_w2r(); gws_pass<SW, 2 * pw>(rec, lane, TP1); gws_r2w();
+      static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA<SW>(rec, lane, j, g2[j]); gws_putB<SW>(rec, lane, j, a1[j]); });
+      gws_putB<SW>(rec, lane, H / 2, f2{1.f, 0.f});
+      gws_w2r(); gws_pass<SW>(rec, lane, TP2); gws_r2w();
+    }
+    // x = [m(dst) | ...] (main.py:155): d/dm += W1[:, :d]^T G1 and the latent columns of dW1 += G1 (x) m, once per bus
+    bwd_inputs<(D + 3) / 4, H>(pnb + NLay2<PIN, H>::total, G1, [&](auto ip_, f2 v) {
+      constexpr int ip = decltype(ip_)::value;
+      if constexpr (ip < D / 2) macc[ip] += v;
+    });
+    static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA<SW>(rec, lane, j, G1[j]); });
+    static_for<0, NDMF>([&](auto t_) {
+      constexpr int t = decltype(t_)::value;
+      static_for<0, 8>([&](auto j_) { constexpr int j = decltype(j_)::value; if constexpr (8 * t + j < D / 2) gws_putB<SW>(rec, lane, j, m[8 * t + j]); });
+      gws_w2r(); gws_pass<SW>(rec, lane, TPm[t]); gws_r2w();
+    });
+  }
+
+  // the tiles -> the (family, step) block of the workgroup's slab (folded block: W1[H][IN] b1 W2 b2); plain stores
+  __device__ __forceinline__ void flush(const GnsBwdsArgs& A, int lane, float* slab) {
+    const long long koff = A.k;
     constexpr int pb1 = PIN * H, pW2 = pb1 + H, pb2 = pW2 + H * H;
-    float* pb_ = slab + A.g_off[fphi] + koff * A.g_sz[fphi];
+    float* pb_ = slab + A.g_off[PF] + koff * A.g_sz[PF];
     gws_flush(lane, TP1, pb_, [&](int c, int il) {
       if (c >= H) return -1;
       if (il < PIN - D) return c * PIN + D + il;
@@ -433,12 +472,15 @@ struct BwdsFam {
 //                                         latent adjoint (51.4 rows)
 //   2  one kernel    {m, theta, v}       bus-major: every row once, the latent adjoint accumulates in place (30.2 rows); the three
 //                                         families' weights (20 KB) cycle through the 16 KB scalar cache
+// A single-phi model (MULTI false) always runs mode 2: its three L nets share the one hidden sum and the adjoint of that sum is the
+// sum over them (main.py:169-171), so the one phi net is reversed after all three - and its weights (14 KB) fit the scalar cache.
 // A kernel writes ONE X row and ONE latent-adjoint part per bus: slot 2 when it runs L_m, else slot 0 (theta, or theta + v), else 1.
 // Readers (Pb-0 for X, the L_m sweep for the latent adjoint) sum the slots of the mode in the order 2, 0, 1; slot 2 of step K-1
 // exists only in mode 2 (no gradient reaches L_m.{K-1}: in modes 0 and 1 no kernel writes it).
-template <int D, int H, int FAMS>
+template <int D, int H, bool MULTI, int FAMS>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GNS_BWDS_WPE))) gns_bwds_sweep_kernel(GnsBwdsArgs A) {
-  using C = GnsDims<D, H, true>;
+  using C = GnsDims<D, H, MULTI>;
+  static_assert(MULTI || FAMS == 7, "the single phi is reversed after all three L nets");
   constexpr int RB = C::RB, MQ = C::MQ, RBA = 4 + 6 * MQ;
   constexpr bool HAS_T = FAMS & 1, HAS_V = FAMS & 2, HAS_M = FAMS & 4;
   constexpr int SLOT = HAS_M ? 2 : (HAS_T ? 0 : 1);
@@ -462,16 +504,21 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GNS_BWD
   if (HAS_M && lastk) {                    // ... but their blocks of the slab must read as zero
     float* z0 = slab + A.g_off[C::NPHI + 2] + (long long)(K - 1) * A.g_sz[C::NPHI + 2];
     for (int i = lane; i < (int)A.g_sz[C::NPHI + 2]; i += 64) z0[i] = 0.f;
-    float* z1 = slab + A.g_off[2] + (long long)(K - 1) * A.g_sz[2];
-    for (int i = lane; i < (int)A.g_sz[2]; i += 64) z1[i] = 0.f;
+    if constexpr (MULTI) {
+      float* z1 = slab + A.g_off[2] + (long long)(K - 1) * A.g_sz[2];
+      for (int i = lane; i < (int)A.g_sz[2]; i += 64) z1[i] = 0.f;
+    }
     if (!HAS_T && !HAS_V) return;
   }
-  BwdsFam<D, H, 2> fm;
-  BwdsFam<D, H, 0> ft;
-  BwdsFam<D, H, 1> fv;
-  if constexpr (HAS_M) fm.init(A);
-  if constexpr (HAS_T) ft.init(A);
-  if constexpr (HAS_V) fv.init(A);
+  BwdsL<D, H, MULTI, 2> lm;
+  BwdsL<D, H, MULTI, 0> lt;
+  BwdsL<D, H, MULTI, 1> lv;
+  BwdsPhi<D, H, MULTI, MULTI ? 2 : 0> pm;      // phi_m | the single phi
+  BwdsPhi<D, H, MULTI, MULTI ? 1 : 0> pt;      // phi_theta (registration order phi_v, phi_theta, phi_m: main.py:113-116)
+  BwdsPhi<D, H, MULTI, 0> pv;                  // phi_v
+  if constexpr (HAS_M) { lm.init(A); pm.init(A); }
+  if constexpr (HAS_T) { lt.init(A); if constexpr (MULTI) pt.init(A); }
+  if constexpr (HAS_V) { lv.init(A); if constexpr (MULTI) pv.init(A); }
   // Step 0 reads m_0 = 0 and produces adjoints of (v, theta, dp, m)_0 that nothing reads (the inputs carry no gradient)
   const bool step0 = k == 0;
   const int par = k & 1, parn = par ^ 1;
@@ -516,22 +563,33 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GNS_BWD
       const int p0 = in_ptr[n], p1 = in_ptr[n + 1];
       xs[0] = f2{s0.x, s0.y}; xs[1] = f2{s0.z, s0.w};
       xs[XL - 1] = f2{(float)(p1 - p0), 1.f};             // deg, and the 1 whose column of dW1 is db1
-      if constexpr (HAS_M) { if (!lastk) fm.bus(A, rec, lane, g, n, 0.f, xs, macc, xsum, p0, p1, row_ein); }
-      if constexpr (HAS_T) ft.bus(A, rec, lane, g, n, a0.y, xs, macc, xsum, p0, p1, row_ein);
-      if constexpr (HAS_V) fv.bus(A, rec, lane, g, n, is_gen[n] ? 0.f : a0.x, xs, macc, xsum, p0, p1, row_ein);
+      f2 gS[H / 2];                                       // adjoint of the hidden-vector sum: what every line ending at n receives
+      const float g3v = is_gen[n] ? 0.f : a0.x;
+      if constexpr (MULTI) {
+        if constexpr (HAS_M) { if (!lastk) { lm.template bus<false>(A, rec, lane, g, n, 0.f, xs, macc, xsum, gS); pm.bus(A, rec, lane, xs, gS, macc, p0, p1, row_ein); } }
+        if constexpr (HAS_T) { lt.template bus<false>(A, rec, lane, g, n, a0.y, xs, macc, xsum, gS); pt.bus(A, rec, lane, xs, gS, macc, p0, p1, row_ein); }
+        if constexpr (HAS_V) { lv.template bus<false>(A, rec, lane, g, n, g3v, xs, macc, xsum, gS); pv.bus(A, rec, lane, xs, gS, macc, p0, p1, row_ein); }
+      } else {
+#pragma unroll
+        for (int j = 0; j < H / 2; ++j) gS[j] = f2{0.f, 0.f};
+        if (!lastk) lm.template bus<true>(A, rec, lane, g, n, 0.f, xs, macc, xsum, gS);
+        lt.template bus<true>(A, rec, lane, g, n, a0.y, xs, macc, xsum, gS);
+        lv.template bus<true>(A, rec, lane, g, n, g3v, xs, macc, xsum, gS);
+        pm.bus(A, rec, lane, xs, gS, macc, p0, p1, row_ein);
+      }
       if (!step0) {
         *row_ptr(A.adj, ar + 1 + SLOT, lane) = xsum;
         store_pairs<D>(A.adj, ar + 4 + (par * 3 + SLOT) * MQ, lane, macc);
       }
     }
   }
-  if constexpr (HAS_M) { if (!lastk) fm.flush(A, lane, slab); }
-  if constexpr (HAS_T) ft.flush(A, lane, slab);
-  if constexpr (HAS_V) fv.flush(A, lane, slab);
+  if constexpr (HAS_M) { if (!lastk) lm.flush(A, lane, slab); if (MULTI ? !lastk : true) pm.flush(A, lane, slab); }
+  if constexpr (HAS_T) { lt.flush(A, lane, slab); if constexpr (MULTI) pt.flush(A, lane, slab); }
+  if constexpr (HAS_V) { lv.flush(A, lane, slab); if constexpr (MULTI) pv.flush(A, lane, slab); }
 }
 
 int gns_bwds_supported(int d, int h, int multi) {
-  if (!multi) return 0;
+  (void)multi;                                  // three phi nets: modes 0-2; the single phi: the bus-major kernel
 #define GNS_CASE(DD, HH) if (d == DD && h == HH) return 1;
   GNS_FOR_EACH_DIMS(GNS_CASE)
 #undef GNS_CASE
@@ -551,15 +609,16 @@ int gns_launch_bwds_phys(const GnsBwdsArgs& A, size_t lds, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? GNS_OK : GNS_ELAUNCH;
 }
 
-int gns_launch_bwds_sweep(int d, int h, const GnsBwdsArgs& A, hipStream_t st) {
+int gns_launch_bwds_sweep(int d, int h, int multi, const GnsBwdsArgs& A, hipStream_t st) {
   const long long GB = (A.G + A.R - 1) / A.R;
   const unsigned blocks = (unsigned)(GB * A.C);
-#define GNS_SWEEP(DD, HH, FAMS) hipLaunchKernelGGL((gns_bwds_sweep_kernel<DD, HH, FAMS>), dim3(blocks), dim3(64), 0, st, A)
+#define GNS_SWEEP(DD, HH, MM, FAMS) hipLaunchKernelGGL((gns_bwds_sweep_kernel<DD, HH, MM, FAMS>), dim3(blocks), dim3(64), 0, st, A)
 #define GNS_CASE(DD, HH)                                                                                                    \
   if (d == DD && h == HH) {                                                                                                 \
-    if (A.mode == 2) GNS_SWEEP(DD, HH, 7);                                                                                  \
-    else if (A.mode == 1) { GNS_SWEEP(DD, HH, 4); GNS_SWEEP(DD, HH, 3); }                                                   \
-    else { GNS_SWEEP(DD, HH, 4); GNS_SWEEP(DD, HH, 1); GNS_SWEEP(DD, HH, 2); }                                              \
+    if (!multi) { if (A.mode != 2) return GNS_EINVAL; GNS_SWEEP(DD, HH, false, 7); }                                        \
+    else if (A.mode == 2) GNS_SWEEP(DD, HH, true, 7);                                                                       \
+    else if (A.mode == 1) { GNS_SWEEP(DD, HH, true, 4); GNS_SWEEP(DD, HH, true, 3); }                                       \
+    else { GNS_SWEEP(DD, HH, true, 4); GNS_SWEEP(DD, HH, true, 1); GNS_SWEEP(DD, HH, true, 2); }                            \
     return hipGetLastError() == hipSuccess ? GNS_OK : GNS_ELAUNCH;                                                          \
   }
   GNS_FOR_EACH_DIMS(GNS_CASE)

@@ -323,7 +323,11 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
         constexpr int l = L0 + j;
         constexpr int fphi = MULTI ? (l == 0 ? 1 : (l == 1 ? 0 : 2)) : 0;
         constexpr int js = MULTI ? j : 0;                   // the single phi: one sum serves all three L nets (main.py:169-171)
+#ifndef GNS_ABLATE_MSG_SAVE      // diagnostic: the hidden sums are not saved (the backward would have to recompute them): what their 1.1 GB of writes cost the forward
         if (A.save && (MULTI || l == 0))
+#else
+        if (false)
+#endif
           store_pairs_nt<H>(A.msg, ((((long long)k * A.G + g) * N + n) * C::NPHI + fphi) * C::HQ, lane, S[js]);
         f2 x[(C::LF_IN + 1) / 2];                           // [v theta | dp dq | m | sum h | deg]
         x[0] = f2{s0.x, s0.y}; x[1] = f2{s0.z, s0.w};

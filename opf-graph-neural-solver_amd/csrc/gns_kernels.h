@@ -102,5 +102,5 @@ struct GnsBwdsArgs {
 int gns_bwds_supported(int d, int h, int multi);
 size_t gns_bwds_phys_lds(int N, int* use_plane);
 int gns_launch_bwds_phys(const GnsBwdsArgs& A, size_t lds, hipStream_t st);
-int gns_launch_bwds_sweep(int d, int h, const GnsBwdsArgs& A, hipStream_t st);
+int gns_launch_bwds_sweep(int d, int h, int multi, const GnsBwdsArgs& A, hipStream_t st);
 int gns_bwds_init_device();
