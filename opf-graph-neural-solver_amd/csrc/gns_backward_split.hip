@@ -19,6 +19,12 @@
 #include "gns_dw.h"
 
 typedef int gns_i8v __attribute__((ext_vector_type(8)));   // one line record of TH_EREC
+#ifndef GNS_BWDS_ONE_LAYOUT
+#define GNS_BWDS_ONE_LAYOUT 0  // 1: recomputation AND data gradients stream the forward layouts (gns_device.h, bwd_from_fwd_layout): one copy of every
+                               //    matrix in the scalar cache (11 KB instead of 20 KB for three families).  0 (default): data gradients from the
+                               //    transposed N-stream copies, like the persistent kernels.  Measured equal within noise in every mode and
+                               //    configuration (profiles/r03/ablation_split.txt E): the option stays for kernels that run more families at once
+#endif
 #ifndef GNS_BWDS_WPE
 #define GNS_BWDS_WPE 2          // waves per SIMD the sweep kernels are compiled for.  Measured (case118 x 16384): 3 (168 registers, 12 bus
                                 // chunks per group) is 8 % SLOWER than 2 - the sweeps are bound by the rows they stream, not by latency
@@ -283,7 +289,10 @@ struct BwdsL : BwdsShape<D, H, MULTI> {
     const long long koff = A.k;
     nb = (cfp)A.pn + A.n_off[C::NPHI + l] + koff * A.n_sz[C::NPHI + l];
     ptl = (cfp)A.pt + A.t_off[C::NPHI + l] + koff * A.t_sz[C::NPHI + l];
-    scalar_cache_warm(ptl, A.t_sz[C::NPHI + l]); scalar_cache_warm(nb, A.n_sz[C::NPHI + l]);
+    scalar_cache_warm(ptl, A.t_sz[C::NPHI + l]);
+#if !GNS_BWDS_ONE_LAYOUT
+    scalar_cache_warm(nb, A.n_sz[C::NPHI + l]);
+#endif
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < NB1; ++t) T1[t] = z4;
@@ -302,14 +311,30 @@ struct BwdsL : BwdsShape<D, H, MULTI> {
     load_pairs<H>(A.msg, ((((long long)A.k * A.G + g) * A.N + n) * C::NPHI + fphi) * C::HQ, lane, S);
     WFirst wf;
     f2 a1[H / 2], a2[H / 2], g2[H / 2], g1[H / 2];
+    using TL = TLay<LIN, H, OUTP>;                 // the forward layout of the block: W1t b1 W2t b2 W4t b4
+#if GNS_BWDS_ONE_LAYOUT
+    (void)wf;
+    mlp2_fwd<LIN, H>(ptl, xs, a1, a2);
+#else
     mlp2_fwd<LIN, H>(ptl, xs, a1, a2, NoBG{}, L0{nullptr, nb, &wf});
+    using LKm = L2; using LKs = std::conditional_t<FOLD4, L1, L2>;
+#endif
     // output layer: g2 = (W4^T g3) * lrelu'(a2);  dW4 | db4 += g3 (x) [a2 | 1]
+#if GNS_BWDS_ONE_LAYOUT
     if constexpr (l == 2) {
-      bwd_rows<OUTP, H>(nb, macc, g2, NoBG{}, L2{&wf, nullptr, nullptr});       // m += L_m (main.py:188); a pass follows
+      bwd_rows_fwd_layout<H, OUTP>(ptl + TL::oW4, macc, g2);                      // m += L_m (main.py:188): g3 = mbar_{k+1}
     } else {
       const f2 g3v[1] = {f2{g3s, 0.f}};                                           // theta += L_theta (:182); v only without a generator (:184-186)
-      bwd_rows<2, H>(nb, g3v, g2, NoBG{}, std::conditional_t<FOLD4, L1, L2>{&wf, nb + NL::oW2, &wf});
+      bwd_rows_fwd_layout<H, 2>(ptl + TL::oW4, g3v, g2);
     }
+#else
+    if constexpr (l == 2) {
+      bwd_rows<OUTP, H>(nb, macc, g2, NoBG{}, LKm{&wf, nullptr, nullptr});      // m += L_m (main.py:188); a pass follows
+    } else {
+      const f2 g3v[1] = {f2{g3s, 0.f}};                                           // theta += L_theta (:182); v only without a generator (:184-186)
+      bwd_rows<2, H>(nb, g3v, g2, NoBG{}, LKs{&wf, nb + NL::oW2, &wf});
+    }
+#endif
 #pragma unroll
     for (int u = 0; u < H / 2; ++u) g2[u] = g2[u] * dlrelu2(a2[u]);
     if constexpr (FOLD4 || FOLDM) {                   // parked at columns 16..26 until the last dW1 window contracts them
@@ -333,7 +358,11 @@ struct BwdsL : BwdsShape<D, H, MULTI> {
       });
     }
     // hidden layer: g1 = (W2^T g2) * lrelu'(a1);  dW2 | db2 += g2 (x) [a1 | 1]
+#if GNS_BWDS_ONE_LAYOUT
+    bwd_rows_fwd_layout<H, H>(ptl + TL::oW2, g2, g1);
+#else
     bwd_rows<H, H>(nb + NL::oW2, g2, g1, NoBG{}, std::conditional_t<FOLD4, L2, NoLink>{&wf, nullptr, nullptr});
+#endif
 #pragma unroll
     for (int u = 0; u < H / 2; ++u) g1[u] = g1[u] * dlrelu2(a1[u]);
     static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA<SW>(rec, lane, j, g2[j]); gws_putB<SW>(rec, lane, j, a1[j]); });
@@ -350,13 +379,18 @@ struct BwdsL : BwdsShape<D, H, MULTI> {
       gws_w2r(); gws_pass<SW, (WIDE && t == NB1 - 1) ? W2OFF : 0>(rec, lane, T1[t]); gws_r2w();
     });
     // input adjoints, four at a time, straight to their consumers
-    bwd_inputs<(LIN + 3) / 4, H>(nb + NL::total, g1, [&](auto ip_, f2 v) {
+    auto to_consumers = [&](auto ip_, f2 v) {
       constexpr int ip = decltype(ip_)::value;
       if constexpr (ip == 0) { xsum.x += v.x; xsum.y += v.y; }
       else if constexpr (ip == 1) xsum.z += v.x;
       else if constexpr (ip < SOFF) macc[ip - 2] += v;
       else if constexpr (ip < SOFF + H / 2) { if constexpr (ACC_GS) gS[ip - SOFF] += v; else gS[ip - SOFF] = v; }
-    });
+    };
+#if GNS_BWDS_ONE_LAYOUT
+    bwd_from_fwd_layout<2 * (SOFF + H / 2), H, cf16p>(ptl, g1, to_consumers);      // the rows of [v theta dp dq | m | sum h]: deg carries no adjoint
+#else
+    bwd_inputs<(LIN + 3) / 4, H>(nb + NL::total, g1, to_consumers);
+#endif
   }
 
   // the tiles -> the (family, step) block of the workgroup's slab (folded block: W1[H][IN] b1 W2 b2 W4 b4); plain stores
@@ -397,7 +431,10 @@ struct BwdsPhi : BwdsShape<D, H, MULTI> {
     const long long koff = A.k;
     pnb = (cfp)A.pn + A.n_off[PF] + koff * A.n_sz[PF];
     ptb = (cfp)A.pt + A.t_off[PF] + koff * A.t_sz[PF];
-    scalar_cache_warm(ptb, A.t_sz[PF]); scalar_cache_warm(pnb, A.n_sz[PF]);
+    scalar_cache_warm(ptb, A.t_sz[PF]);
+#if !GNS_BWDS_ONE_LAYOUT
+    scalar_cache_warm(pnb, A.n_sz[PF]);
+#endif
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < NDM; ++t) TPm[t] = z4;
@@ -411,6 +448,7 @@ struct BwdsPhi : BwdsShape<D, H, MULTI> {
     const float* IN = A.in;
     const f2 (&m)[D / 2] = reinterpret_cast<const f2 (&)[D / 2]>(xs[2]);
     WFirst wf;
+    (void)wf;
     f2 uh[H / 2], G1[H / 2];
     if constexpr (WIDE)                               // the latent tail, parked behind [line parameters | 1] at columns 16..21
       static_for<0, (D - 16) / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putB<SW>(rec, lane, 8 + (PIN - D + 2) / 2 + j, m[8 + j]); });
@@ -421,10 +459,17 @@ struct BwdsPhi : BwdsShape<D, H, MULTI> {
       const f4 ea = *row_ptr(IN, row_ein + 3LL * p, lane), eb = *row_ptr(IN, row_ein + 3LL * p + 1, lane);
       const f2 xt[3] = {f2{ea.x, ea.y}, f2{ea.z, ea.w}, f2{eb.x, 0.f}};
       f2 a1[H / 2], a2[H / 2], g2[H / 2], g1[H / 2];
+#if GNS_BWDS_ONE_LAYOUT
+      phi_tail<PIN, H, D>(ptb, uh, xt, a1, a2);
+#pragma unroll
+      for (int u = 0; u < H / 2; ++u) g2[u] = gS[u] * dlrelu2(a2[u]);
+      bwd_rows_fwd_layout<H, H>(ptb + TLay2<PIN, H>::oW2, g2, g1);
+#else
       phi_tail<PIN, H, D>(ptb, uh, xt, a1, a2, NoBG{}, L0{nullptr, pnb, &wf});
 #pragma unroll
       for (int u = 0; u < H / 2; ++u) g2[u] = gS[u] * dlrelu2(a2[u]);
       bwd_rows<H, H>(pnb, g2, g1, NoBG{}, L2{&wf, nullptr, nullptr});
+#endif
 #pragma unroll
       for (int u = 0; u < H / 2; ++u) { g1[u] = g1[u] * dlrelu2(a1[u]); G1[u] += g1[u]; }
       constexpr int pw = WIDE ? 8 : 0;                // wide window: the line's pass contracts columns 16..31
@@ -436,10 +481,14 @@ struct BwdsPhi : BwdsShape<D, H, MULTI> {
       gws_w2r(); gws_pass<SW>(rec, lane, TP2); gws_r2w();
     }
     // x = [m(dst) | ...] (main.py:155): d/dm += W1[:, :d]^T G1 and the latent columns of dW1 += G1 (x) m, once per bus
+#if GNS_BWDS_ONE_LAYOUT
+    bwd_from_fwd_layout<D, H, cf16p>(ptb, G1, [&](auto ip_, f2 v) { macc[decltype(ip_)::value] += v; });   // the latent rows of W1t
+#else
     bwd_inputs<(D + 3) / 4, H>(pnb + NLay2<PIN, H>::total, G1, [&](auto ip_, f2 v) {
       constexpr int ip = decltype(ip_)::value;
       if constexpr (ip < D / 2) macc[ip] += v;
     });
+#endif
     static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA<SW>(rec, lane, j, G1[j]); });
     static_for<0, NDMF>([&](auto t_) {
       constexpr int t = decltype(t_)::value;

@@ -440,6 +440,33 @@ __device__ __forceinline__ void mlp2_bwd(cfp blk, const f2 (&a1)[H / 2], const f
   pin_all(gx);
 }
 
+// ---- data gradients from the FORWARD layouts (split backward) ----------------------------------------------------------------------
+// The backward recomputes a network's hidden activations from the forward layouts (W1t[in][out], W2t, W4t) and then needs the same
+// matrices transposed for the data gradients.  Streaming a second, transposed copy (the N-stream) doubles the network's footprint in
+// the 16 KB scalar cache; these read the forward layout instead: a row of W[in][out] holds all outputs of ONE input, so an (aligned)
+// weight pair is two OUTPUTS and the packed FMA multiplies element-wise with the adjoint pair (no broadcast) into a two-lane partial
+// sum per input; the lanes are added when the row ends.  The recomputation stays bit-identical to the forward pass (LeakyReLU's
+// derivative is taken on exactly the forward's activations); the data gradients change by rounding only (another summation order).
+//   gin[NO] -> sum_j W[i][j] gin[j] for i = 0..NI-1 (NI even), handed to sink(ic<i / 2>, f2{value_i, value_i+1}) as each pair completes
+template <int NI, int NO, class VP = cf16up, class F>
+__device__ __forceinline__ void bwd_from_fwd_layout(cfp wt, const f2 (&gin)[NO / 2], F&& sink) {
+  static_assert(NI % 2 == 0 && NO % 2 == 0, "pairs");
+  f2 acc = {0.f, 0.f};
+  float even = 0.f;
+  stream_pairs<NI * NO, VP>(wt, [&](auto w_, f2 s) {
+    constexpr int w = decltype(w_)::value, i = w / NO, jp = (w % NO) / 2;
+    acc = (jp == 0) ? s * gin[0] : __builtin_elementwise_fma(s, gin[jp], acc);
+    if constexpr (jp == NO / 2 - 1) {
+      if constexpr (i % 2 == 0) { even = acc.x + acc.y; asm volatile("" : "+v"(even)); }
+      else { f2 v = f2{even, acc.x + acc.y}; pin(v); sink(std::integral_constant<int, i / 2>{}, v); }
+    }
+  });
+}
+template <int NI, int NO, class VP = cf16up>
+__device__ __forceinline__ void bwd_rows_fwd_layout(cfp wt, const f2 (&gin)[NO / 2], f2 (&gout)[NI / 2]) {
+  bwd_from_fwd_layout<NI, NO, VP>(wt, gin, [&](auto ip_, f2 v) { gout[decltype(ip_)::value] = v; });
+}
+
 // ---- layer-wise data path of the backward (used where each layer's weight gradient is contracted as soon as its operands exist) ----
 // gout[i] = sum_j Wn[j][i] gin[j] from an [NJ][H] stream (output layer and hidden layer of the data path)
 template <int NJP, int H, class BG = NoBG, class LK = NoLink>
