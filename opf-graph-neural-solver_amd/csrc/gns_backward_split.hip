@@ -311,7 +311,7 @@ struct BwdsL : BwdsShape<D, H, MULTI> {
     load_pairs<H>(A.msg, ((((long long)A.k * A.G + g) * A.N + n) * C::NPHI + fphi) * C::HQ, lane, S);
     WFirst wf;
     f2 a1[H / 2], a2[H / 2], g2[H / 2], g1[H / 2];
-    using TL = TLay<LIN, H, OUTP>;                 // the forward layout of the block: W1t b1 W2t b2 W4t b4
+    using TL [[maybe_unused]] = TLay<LIN, H, OUTP>;   // the forward layout of the block: W1t b1 W2t b2 W4t b4
 #if GNS_BWDS_ONE_LAYOUT
     (void)wf;
     mlp2_fwd<LIN, H>(ptl, xs, a1, a2);
