@@ -225,7 +225,7 @@ def main():
         tmax = torch.tensor([dt_], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        return float(tmax.item()), tot_
+        return float(tmax.item()), tot_.detach().mean()           # (detached: no autograd graph outlives the step)
 
     for _ in range(a.warmup):
         step()
@@ -235,7 +235,7 @@ def main():
     lib.gns_profile_read(0, ctypes.byref(ms_f), ctypes.byref(n_f))
     lib.gns_profile_read(1, ctypes.byref(ms_b), ctypes.byref(n_b))
     lib.gns_profile_enable(0)
-    final_loss = float(tot.mean().item())
+    final_loss = float(tot.item())
     packed_hits = model._resident['hits'] if model._resident is not None else 0
     # the same step without the resident copy: inputs are packed by gns_pack_inputs_kernel inside every forward call
     model.unbind_dataset()
@@ -248,6 +248,24 @@ def main():
         sdt, _ = timed(a.sustained_steps)
         sustained = {'steps': a.sustained_steps, 'value': round(bt * world * a.sustained_steps / sdt, 1), 'unit': 'grids/s',
                      'ms_per_step': round(sdt / a.sustained_steps * 1e3, 4)}
+    # The same step as ONE captured HIP graph (training.GraphedStep on the resident, bound batch; one process only): what a loop gains
+    # when launch gaps matter (config 2: -10 %, config 3: nothing).  Reported beside the eager headline, never instead of it.
+    captured = None
+    if world == 1 and a.sustained_steps > 0:
+        try:
+            gstep = amd.training.GraphedStep(model, opt, buses, lines, gens, copy_inputs=False)
+            for _ in range(3):
+                gstep.run(buses, lines, gens)
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                gstep.run(buses, lines, gens)
+            fence()
+            gdt = time.perf_counter() - t1
+            captured = {'ms_per_step': round(gdt / a.steps * 1e3, 4), 'value': round(bt * a.steps / gdt, 1), 'unit': 'grids/s'}
+            del gstep
+        except Exception as e:                       # never let the extra measurement break the contract line
+            captured = {'error': str(e)[:200]}
     # forward-only throughput (evaluation mode), not part of the headline value
     with torch.no_grad():
         for _ in range(2):
@@ -307,6 +325,7 @@ def main():
             'kernels_ms': {kfwd: round(fwd_ms, 4), kbwd: round(bwd_ms, 4)},
             'glue_ms_per_step': round(dt / a.steps * 1e3 - fwd_ms - bwd_ms, 4),
             'sustained': sustained,
+            'captured_graph_step': captured,
             'forward_only_grids_per_s': round(fwd_only * world, 1),
             'final_mean_total_loss': final_loss,
         }
