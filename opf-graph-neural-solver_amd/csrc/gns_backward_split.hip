@@ -282,7 +282,8 @@ struct BwdsL : BwdsShape<D, H, MULTI> {
   static constexpr bool FOLD4 = WIDE && l < 2 && XT + H + 1 <= 16;                           // [x tail | a2 | 1] fits one window
   static constexpr bool FOLDM = GwSubWide::NA >= 16 && WIDE && l == 2 && XT + H + 1 <= 16 && H + (OUT - 16) <= 16;
 
-  f32x4 T1[NB1], T2, T4[NA4];
+  static constexpr int NT4 = FOLD4 ? 1 : (FOLDM ? 1 : NA4);      // tiles the output layer really uses (folded: none / one)
+  f32x4 T1[NB1], T2, T4[NT4];
   cfp nb, ptl;
 
   __device__ __forceinline__ void init(const GnsBwdsArgs& A) {
@@ -297,14 +298,14 @@ struct BwdsL : BwdsShape<D, H, MULTI> {
 #pragma unroll
     for (int t = 0; t < NB1; ++t) T1[t] = z4;
 #pragma unroll
-    for (int t = 0; t < NA4; ++t) T4[t] = z4;
+    for (int t = 0; t < NT4; ++t) T4[t] = z4;
     T2 = z4;
   }
 
   // xs = [v theta | dp dq | m | (the hidden sum this net reads goes here) | deg, 1]; g3s = the upstream of the scalar output (L_theta:
   // thbar, L_v: vbar or 0 on a generator bus); L_m takes macc = d/dm_{k+1} as its upstream.  xsum (d/dv, d/dtheta, d/ddp of the L
   // inputs) and macc (d/dm) accumulate; gS = the adjoint of the hidden sum: assigned (ACC_GS false) or accumulated (the single phi).
-  template <bool ACC_GS>
+  template <bool ACC_GS, bool STEP0>
   __device__ __forceinline__ void bus(const GnsBwdsArgs& A, float* rec, int lane, long long g, int n, float g3s, f2 (&xs)[XL],
                                       f2 (&macc)[D / 2], f4& xsum, f2 (&gS)[H / 2]) {
     f2 (&S)[H / 2] = reinterpret_cast<f2 (&)[H / 2]>(xs[SOFF]);
@@ -316,8 +317,18 @@ struct BwdsL : BwdsShape<D, H, MULTI> {
     (void)wf;
     mlp2_fwd<LIN, H>(ptl, xs, a1, a2);
 #else
-    mlp2_fwd<LIN, H>(ptl, xs, a1, a2, NoBG{}, L0{nullptr, nb, &wf});
-    using LKm = L2; using LKs = std::conditional_t<FOLD4, L1, L2>;
+    using LKm = std::conditional_t<STEP0, NoLink, L2>; using LKs = std::conditional_t<STEP0, std::conditional_t<FOLD4, L0, NoLink>, std::conditional_t<FOLD4, L1, L2>>;
+    if constexpr (STEP0) {
+      // m_0 = 0 (main.py:141): the latent rows of W1t multiply zeros - exact zeros, so leaving them out changes no bit.  The first
+      // layer is the four state inputs (phi_head's shape) + the hidden sum, deg, the bias and the second layer (phi_tail's shape).
+      f2 u4[H / 2];
+      const f2 (&st)[2] = reinterpret_cast<const f2 (&)[2]>(xs[0]);
+      const f2 (&tl)[(LIN - 4 - D + 1) / 2] = reinterpret_cast<const f2 (&)[(LIN - 4 - D + 1) / 2]>(xs[SOFF]);
+      phi_head<4, H>(ptl, st, u4);
+      phi_tail<LIN, H, 4 + D>(ptl, u4, tl, a1, a2);
+    } else {
+      mlp2_fwd<LIN, H>(ptl, xs, a1, a2, NoBG{}, L0{nullptr, nb, &wf});
+    }
 #endif
     // output layer: g2 = (W4^T g3) * lrelu'(a2);  dW4 | db4 += g3 (x) [a2 | 1]
 #if GNS_BWDS_ONE_LAYOUT
@@ -389,7 +400,17 @@ struct BwdsL : BwdsShape<D, H, MULTI> {
 #if GNS_BWDS_ONE_LAYOUT
     bwd_from_fwd_layout<2 * (SOFF + H / 2), H, cf16p>(ptl, g1, to_consumers);      // the rows of [v theta dp dq | m | sum h]: deg carries no adjoint
 #else
-    bwd_inputs<(LIN + 3) / 4, H>(nb + NL::total, g1, to_consumers);
+    if constexpr (STEP0) {
+      // step 0: the adjoints of (v, theta, dp, m)_0 feed nothing (the inputs carry no gradient); only the hidden-sum adjoint is
+      // needed, i.e. the groups of four inputs that hold columns SOFF*2 .. SOFF*2 + H - 1 of W1x
+      constexpr int G0 = (2 * SOFF) / 4, G1 = (2 * SOFF + H - 1) / 4 + 1;
+      bwd_inputs<G1 - G0, H>(nb + NL::total + G0 * H * 4, g1, [&](auto ip_, f2 v) {
+        constexpr int ip = decltype(ip_)::value + 2 * G0;
+        if constexpr (ip >= SOFF && ip < SOFF + H / 2) { if constexpr (ACC_GS) gS[ip - SOFF] += v; else gS[ip - SOFF] = v; }
+      });
+    } else {
+      bwd_inputs<(LIN + 3) / 4, H>(nb + NL::total, g1, to_consumers);
+    }
 #endif
   }
 
@@ -424,7 +445,7 @@ struct BwdsPhi : BwdsShape<D, H, MULTI> {
   static constexpr int XL = B::XL, PIN = B::PIN, NDM = B::NDM, NDMF = B::NDMF;
   static constexpr bool WIDE = B::WIDE;
 
-  f32x4 TP1, TP2, TPm[NDM];
+  f32x4 TP1, TP2, TPm[NDMF];
   cfp pnb, ptb;
 
   __device__ __forceinline__ void init(const GnsBwdsArgs& A) {
@@ -437,11 +458,12 @@ struct BwdsPhi : BwdsShape<D, H, MULTI> {
 #endif
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < NDM; ++t) TPm[t] = z4;
+    for (int t = 0; t < NDMF; ++t) TPm[t] = z4;
     TP1 = z4; TP2 = z4;
   }
 
   // back through the hidden vectors of the lines p0..p1 ending at the bus: gS = the adjoint of their sum
+  template <bool STEP0>
   __device__ __forceinline__ void bus(const GnsBwdsArgs& A, float* rec, int lane, const f2 (&xs)[XL], const f2 (&gS)[H / 2],
                                       f2 (&macc)[D / 2], int p0, int p1, long long row_ein) {
     if (p0 >= p1) return;
@@ -452,7 +474,13 @@ struct BwdsPhi : BwdsShape<D, H, MULTI> {
     f2 uh[H / 2], G1[H / 2];
     if constexpr (WIDE)                               // the latent tail, parked behind [line parameters | 1] at columns 16..21
       static_for<0, (D - 16) / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putB<SW>(rec, lane, 8 + (PIN - D + 2) / 2 + j, m[8 + j]); });
-    phi_head<D, H>(ptb, m, uh);
+    // STEP0: m_0 = 0 (main.py:141): the bus share of phi's first layer is exactly zero, and so are d/dm_0's consumers
+    if constexpr (STEP0) {
+#pragma unroll
+      for (int j = 0; j < H / 2; ++j) uh[j] = f2{0.f, 0.f};
+    } else {
+      phi_head<D, H>(ptb, m, uh);
+    }
 #pragma unroll
     for (int j = 0; j < H / 2; ++j) G1[j] = f2{0.f, 0.f};
     for (int p = p0; p < p1; ++p) {
@@ -481,6 +509,7 @@ struct BwdsPhi : BwdsShape<D, H, MULTI> {
       gws_w2r(); gws_pass<SW>(rec, lane, TP2); gws_r2w();
     }
     // x = [m(dst) | ...] (main.py:155): d/dm += W1[:, :d]^T G1 and the latent columns of dW1 += G1 (x) m, once per bus
+    if constexpr (STEP0) return;       // ... both zero at step 0: d/dm_0 is never read and m_0 = 0
 #if GNS_BWDS_ONE_LAYOUT
     bwd_from_fwd_layout<D, H, cf16p>(ptb, G1, [&](auto ip_, f2 v) { macc[decltype(ip_)::value] += v; });   // the latent rows of W1t
 #else
@@ -526,7 +555,7 @@ struct BwdsPhi : BwdsShape<D, H, MULTI> {
 // A kernel writes ONE X row and ONE latent-adjoint part per bus: slot 2 when it runs L_m, else slot 0 (theta, or theta + v), else 1.
 // Readers (Pb-0 for X, the L_m sweep for the latent adjoint) sum the slots of the mode in the order 2, 0, 1; slot 2 of step K-1
 // exists only in mode 2 (no gradient reaches L_m.{K-1}: in modes 0 and 1 no kernel writes it).
-template <int D, int H, bool MULTI, int FAMS>
+template <int D, int H, bool MULTI, int FAMS, bool STEP0>      // STEP0: the instantiation that reverses step 0 (its dead work compiled out)
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GNS_BWDS_WPE))) gns_bwds_sweep_kernel(GnsBwdsArgs A) {
   using C = GnsDims<D, H, MULTI>;
   static_assert(MULTI || FAMS == 7, "the single phi is reversed after all three L nets");
@@ -569,7 +598,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GNS_BWD
   if constexpr (HAS_T) { lt.init(A); if constexpr (MULTI) pt.init(A); }
   if constexpr (HAS_V) { lv.init(A); if constexpr (MULTI) pv.init(A); }
   // Step 0 reads m_0 = 0 and produces adjoints of (v, theta, dp, m)_0 that nothing reads (the inputs carry no gradient)
-  const bool step0 = k == 0;
+  constexpr bool step0 = STEP0;
   const int par = k & 1, parn = par ^ 1;
   const bool m2_live = (A.mode == 2) || k + 1 < K - 1;      // slot 2 of step k+1 was written
   const long long R = gns_in_rows(N, E);
@@ -615,18 +644,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GNS_BWD
       f2 gS[H / 2];                                       // adjoint of the hidden-vector sum: what every line ending at n receives
       const float g3v = is_gen[n] ? 0.f : a0.x;
       if constexpr (MULTI) {
-        if constexpr (HAS_M) { if (!lastk) { lm.template bus<false>(A, rec, lane, g, n, 0.f, xs, macc, xsum, gS); pm.bus(A, rec, lane, xs, gS, macc, p0, p1, row_ein); } }
-        if constexpr (HAS_T) { lt.template bus<false>(A, rec, lane, g, n, a0.y, xs, macc, xsum, gS); pt.bus(A, rec, lane, xs, gS, macc, p0, p1, row_ein); }
-        if constexpr (HAS_V) { lv.template bus<false>(A, rec, lane, g, n, g3v, xs, macc, xsum, gS); pv.bus(A, rec, lane, xs, gS, macc, p0, p1, row_ein); }
+        if constexpr (HAS_M) { if (!lastk) { lm.template bus<false, STEP0>(A, rec, lane, g, n, 0.f, xs, macc, xsum, gS); pm.template bus<STEP0>(A, rec, lane, xs, gS, macc, p0, p1, row_ein); } }
+        if constexpr (HAS_T) { lt.template bus<false, STEP0>(A, rec, lane, g, n, a0.y, xs, macc, xsum, gS); pt.template bus<STEP0>(A, rec, lane, xs, gS, macc, p0, p1, row_ein); }
+        if constexpr (HAS_V) { lv.template bus<false, STEP0>(A, rec, lane, g, n, g3v, xs, macc, xsum, gS); pv.template bus<STEP0>(A, rec, lane, xs, gS, macc, p0, p1, row_ein); }
       } else {
 #pragma unroll
         for (int j = 0; j < H / 2; ++j) gS[j] = f2{0.f, 0.f};
-        if (!lastk) lm.template bus<true>(A, rec, lane, g, n, 0.f, xs, macc, xsum, gS);
-        lt.template bus<true>(A, rec, lane, g, n, a0.y, xs, macc, xsum, gS);
-        lv.template bus<true>(A, rec, lane, g, n, g3v, xs, macc, xsum, gS);
-        pm.bus(A, rec, lane, xs, gS, macc, p0, p1, row_ein);
+        if (!lastk) lm.template bus<true, STEP0>(A, rec, lane, g, n, 0.f, xs, macc, xsum, gS);
+        lt.template bus<true, STEP0>(A, rec, lane, g, n, a0.y, xs, macc, xsum, gS);
+        lv.template bus<true, STEP0>(A, rec, lane, g, n, g3v, xs, macc, xsum, gS);
+        pm.template bus<STEP0>(A, rec, lane, xs, gS, macc, p0, p1, row_ein);
       }
-      if (!step0) {
+      if constexpr (!step0) {
         *row_ptr(A.adj, ar + 1 + SLOT, lane) = xsum;
         store_pairs<D>(A.adj, ar + 4 + (par * 3 + SLOT) * MQ, lane, macc);
       }
@@ -661,7 +690,8 @@ int gns_launch_bwds_phys(const GnsBwdsArgs& A, size_t lds, hipStream_t st) {
 int gns_launch_bwds_sweep(int d, int h, int multi, const GnsBwdsArgs& A, hipStream_t st) {
   const long long GB = (A.G + A.R - 1) / A.R;
   const unsigned blocks = (unsigned)(GB * A.C);
-#define GNS_SWEEP(DD, HH, MM, FAMS) hipLaunchKernelGGL((gns_bwds_sweep_kernel<DD, HH, MM, FAMS>), dim3(blocks), dim3(64), 0, st, A)
+#define GNS_SWEEP(DD, HH, MM, FAMS) do { if (A.k == 0) hipLaunchKernelGGL((gns_bwds_sweep_kernel<DD, HH, MM, FAMS, true>), dim3(blocks), dim3(64), 0, st, A); \
+                                         else hipLaunchKernelGGL((gns_bwds_sweep_kernel<DD, HH, MM, FAMS, false>), dim3(blocks), dim3(64), 0, st, A); } while (0)
 #define GNS_CASE(DD, HH)                                                                                                    \
   if (d == DD && h == HH) {                                                                                                 \
     if (!multi) { if (A.mode != 2) return GNS_EINVAL; GNS_SWEEP(DD, HH, false, 7); }                                        \
