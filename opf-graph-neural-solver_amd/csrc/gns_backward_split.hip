@@ -574,6 +574,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GNS_BWD
   const int c = (int)(bid / GB);
   const int N = A.N, E = A.E, K = A.K, k = A.k;
   cip topo = (cip)A.topo;
+  // (a partition of its own for the {L_theta, L_v} kernel, with generator buses at half weight, measured no better: 2.02 vs 2.00 ms)
   const cip part = topo + topo[TH_PART] + A.part_idx * (GNS_MAXP + 1), in_ptr = topo + topo[TH_IN_PTR], is_gen = topo + topo[TH_IS_GEN];
   const int n0 = part[c], n1 = part[c + 1];
   const long long g0 = gb * A.R, g1 = (g0 + A.R < A.G) ? g0 + A.R : A.G;
@@ -646,13 +647,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GNS_BWD
       if constexpr (MULTI) {
         if constexpr (HAS_M) { if (!lastk) { lm.template bus<false, STEP0>(A, rec, lane, g, n, 0.f, xs, macc, xsum, gS); pm.template bus<STEP0>(A, rec, lane, xs, gS, macc, p0, p1, row_ein); } }
         if constexpr (HAS_T) { lt.template bus<false, STEP0>(A, rec, lane, g, n, a0.y, xs, macc, xsum, gS); pt.template bus<STEP0>(A, rec, lane, xs, gS, macc, p0, p1, row_ein); }
-        if constexpr (HAS_V) { lv.template bus<false, STEP0>(A, rec, lane, g, n, g3v, xs, macc, xsum, gS); pv.template bus<STEP0>(A, rec, lane, xs, gS, macc, p0, p1, row_ein); }
+        // v moves only on buses without a generator (main.py:184-186): on a generator bus the upstream of L_v is exactly zero, and with
+        // it every adjoint and every weight-gradient term of L_v and of phi_v over the lines ending there - the bus is skipped (the
+        // topology is the same for all 64 grids of the wave, so the branch is uniform).  46 % of case118's buses carry a generator.
+        if constexpr (HAS_V) { if (!is_gen[n]) { lv.template bus<false, STEP0>(A, rec, lane, g, n, g3v, xs, macc, xsum, gS); pv.template bus<STEP0>(A, rec, lane, xs, gS, macc, p0, p1, row_ein); } }
       } else {
 #pragma unroll
         for (int j = 0; j < H / 2; ++j) gS[j] = f2{0.f, 0.f};
         if (!lastk) lm.template bus<true, STEP0>(A, rec, lane, g, n, 0.f, xs, macc, xsum, gS);
         lt.template bus<true, STEP0>(A, rec, lane, g, n, a0.y, xs, macc, xsum, gS);
-        lv.template bus<true, STEP0>(A, rec, lane, g, n, g3v, xs, macc, xsum, gS);
+        if (!is_gen[n]) lv.template bus<true, STEP0>(A, rec, lane, g, n, g3v, xs, macc, xsum, gS);     // (a generator bus: L_v's upstream is zero, see above)
         pm.template bus<STEP0>(A, rec, lane, xs, gS, macc, p0, p1, row_ein);
       }
       if constexpr (!step0) {
