@@ -78,10 +78,11 @@ __global__ void __launch_bounds__(GNS_BWDS_PHYS_THREADS) gns_bwds_phys_kernel(Gn
 
   // ---------------- Pb-0: closes step k+1 (identity paths + the input adjoints its sweeps collected), loss term ----------
   float lb = 0.f;
-  for (int nb = n0; nb < n1; nb += 2) {
-    f4 s1[2], a0[2], x0[2], x1[2], x2[2], b1[2];
+  constexpr int PB = 4;                        // buses per round: their row loads fly together
+  for (int nb = n0; nb < n1; nb += PB) {
+    f4 s1[PB], a0[PB], x0[PB], x1[PB], x2[PB], b1[PB];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < PB; ++j) {
       const int n = min(nb + j, n1 - 1);
       const long long ar = adj_row(n);
       s1[j] = *row_ptr(A.state, state_row(k + 1, n), lane);
@@ -96,7 +97,7 @@ __global__ void __launch_bounds__(GNS_BWDS_PHYS_THREADS) gns_bwds_phys_kernel(Gn
       }
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < PB; ++j) {
       const int n = nb + j;
       if (n < n1) {
         f4 a;
@@ -131,32 +132,37 @@ __global__ void __launch_bounds__(GNS_BWDS_PHYS_THREADS) gns_bwds_phys_kernel(Gn
   const float pgbar = lbar / (low1 ? 2.f * (gsum.y - gsum.z) : 2.f * (gsum.w - gsum.y));   // d lambda / d p_global (main.py:47-51)
 
   // ---------------- line phase: per line, the adjoints of the line physics w.r.t. v, theta of its 2 (+4) buses ------------
+  // Two lines per iteration: the row / LDS loads of both are issued before either is evaluated (the phase waits on loads).
   {
     const cip erec = topo + topo[TH_EREC];
-    for (int p = e0; p < e1; ++p) {
+    struct EdgeIn { f4 e1v, o0; float vs, ths, vt, tht, tha, thb, thc, thd, Fb, Tb; };
+    auto edge_load = [&](int p, EdgeIn& L) {
       // (s, t, a, b, q, c, d) of the line in one 32-byte scalar load (gns_topology.cpp)
       const gns_i8v r = *reinterpret_cast<const __attribute__((address_space(4))) gns_i8v*>(erec + 8 * p);
       const int s = r[0], t = r[1], ia = r[2], ib = r[3], q = r[4], ic = r[5], id = r[6];
-      const f4 e1v = *row_ptr(IN, row_ein + 3LL * p + 1, lane);             // shift_e, y_s, tau_s, sh_s
-      const f4 o0 = *row_ptr(IN, row_eout + q, lane);                        // y_t, tau_t, sh_t, b_t
-      float vs, ths, vt, tht, tha, thb, thc, thd, Fb, Tb;
+      L.e1v = *row_ptr(IN, row_ein + 3LL * p + 1, lane);                   // shift_e, y_s, tau_s, sh_s
+      L.o0 = *row_ptr(IN, row_eout + q, lane);                              // y_t, tau_t, sh_t, b_t
       if (use_plane) {
-        vs = pl_v[s * GNS_LANES + lane]; ths = pl_th[s * GNS_LANES + lane];
-        vt = pl_v[t * GNS_LANES + lane]; tht = pl_th[t * GNS_LANES + lane];
-        tha = pl_th[ia * GNS_LANES + lane]; thb = pl_th[ib * GNS_LANES + lane];
-        thc = pl_th[ic * GNS_LANES + lane]; thd = pl_th[id * GNS_LANES + lane];
-        if (plane_dp) { Fb = pl_dp[t * GNS_LANES + lane]; Tb = pl_dp[s * GNS_LANES + lane]; }
-        else { Fb = row_ptr(A.adj, adj_row(t), lane)->z; Tb = row_ptr(A.adj, adj_row(s), lane)->z; }
+        L.vs = pl_v[s * GNS_LANES + lane]; L.ths = pl_th[s * GNS_LANES + lane];
+        L.vt = pl_v[t * GNS_LANES + lane]; L.tht = pl_th[t * GNS_LANES + lane];
+        L.tha = pl_th[ia * GNS_LANES + lane]; L.thb = pl_th[ib * GNS_LANES + lane];
+        L.thc = pl_th[ic * GNS_LANES + lane]; L.thd = pl_th[id * GNS_LANES + lane];
+        if (plane_dp) { L.Fb = pl_dp[t * GNS_LANES + lane]; L.Tb = pl_dp[s * GNS_LANES + lane]; }
+        else { L.Fb = row_ptr(A.adj, adj_row(t), lane)->z; L.Tb = row_ptr(A.adj, adj_row(s), lane)->z; }
       } else {
         const f4 ss = *row_ptr(A.state, state_row(k + 1, s), lane), st = *row_ptr(A.state, state_row(k + 1, t), lane);
-        vs = ss.x; ths = ss.y; vt = st.x; tht = st.y;
-        tha = row_ptr(A.state, state_row(k + 1, ia), lane)->y; thb = row_ptr(A.state, state_row(k + 1, ib), lane)->y;
-        thc = row_ptr(A.state, state_row(k + 1, ic), lane)->y; thd = row_ptr(A.state, state_row(k + 1, id), lane)->y;
-        Fb = row_ptr(A.adj, adj_row(t), lane)->z;                            // dp[t] += p_from   (main.py:94)
-        Tb = row_ptr(A.adj, adj_row(s), lane)->z;                            // dp[s] += p_to     (main.py:95)
+        L.vs = ss.x; L.ths = ss.y; L.vt = st.x; L.tht = st.y;
+        L.tha = row_ptr(A.state, state_row(k + 1, ia), lane)->y; L.thb = row_ptr(A.state, state_row(k + 1, ib), lane)->y;
+        L.thc = row_ptr(A.state, state_row(k + 1, ic), lane)->y; L.thd = row_ptr(A.state, state_row(k + 1, id), lane)->y;
+        L.Fb = row_ptr(A.adj, adj_row(t), lane)->z;                          // dp[t] += p_from   (main.py:94)
+        L.Tb = row_ptr(A.adj, adj_row(s), lane)->z;                          // dp[s] += p_to     (main.py:95)
       }
+    };
+    auto edge_adjoint = [&](int p, const EdgeIn& L) {
+      const f4 e1v = L.e1v, o0 = L.o0;
+      const float vs = L.vs, ths = L.ths, vt = L.vt, tht = L.tht, Fb = L.Fb, Tb = L.Tb;
       const float ys = e1v.y, taus = e1v.z, shs = e1v.w;
-      const float dl = tha - thb, dl2 = thd - thc;
+      const float dl = L.tha - L.thb, dl2 = L.thd - L.thc;
       float sA, cA, sB, cB, sD, cD, sC, cC, sD2, cD2;
       sincosf(ths - tht - dl - shs, &sA, &cA);
       sincosf(tht - ths - dl + shs, &sB, &cB);
@@ -185,6 +191,13 @@ __global__ void __launch_bounds__(GNS_BWDS_PHYS_THREADS) gns_bwds_phys_kernel(Gn
       // dtht == -dths bit for bit (Bb - Ab + Cb against Ab - Bb - Cb): plane 3 is not written, the gather negates plane 2
       *slot_ptr(0, p) = dvs; *slot_ptr(1, p) = dvt; *slot_ptr(2, p) = dths;
       *slot_ptr(4, p) = dbar; *slot_ptr(5, p) = dbar2;
+    };
+    for (int p = e0; p < e1; p += 2) {
+      EdgeIn L0, L1;
+      edge_load(p, L0);
+      edge_load(min(p + 1, e1 - 1), L1);
+      edge_adjoint(p, L0);
+      if (p + 1 < e1) edge_adjoint(p + 1, L1);
     }
   }
   __syncthreads();
