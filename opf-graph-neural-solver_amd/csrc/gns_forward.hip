@@ -1,6 +1,9 @@
 // Fused forward of the GNS K-step loop (GNS/main.py:140-202) for gfx950, plus the two layout kernels
 // in front of it.  One launch runs all K steps of 64*gridDim.x grids.
 #include "gns_device.h"
+#ifndef GNS_FWD_GEN_SKIP
+#define GNS_FWD_GEN_SKIP 1          // 0 (diagnostic): L_v / phi_v are computed on generator buses too (their results are discarded)
+#endif
 #include "gns_kernels.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -295,12 +298,21 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
       // main.py:155-163 with the output layer of phi folded into L'.  The latent vector of the destination bus is the
       // same for every line ending here: its share of phi's first layer is computed once per bus (phi_head)
       constexpr int NF = MULTI ? NL : 1;
+#if GNS_FWD_GEN_SKIP
+      // v moves only on buses without a generator (main.py:184-186): on a generator bus L_v's output is discarded, and with three phi
+      // nets so is everything phi_v computes for the lines ending there; the branch is uniform (one topology per wave).  The hidden sum
+      // is then saved as zeros (the persistent backward kernels still multiply it by a zero upstream; the split backward skips it too).
+      const bool skip_v = grp == 0 && is_gen[n] != 0;
+#else
+      const bool skip_v = false;
+#endif
       f2 uh[NF][H / 2];
       if (p0 < p1) {
         static_for<0, NF>([&](auto j_) {
           constexpr int j = decltype(j_)::value;
           constexpr int l = L0 + j;
           constexpr int fphi = MULTI ? (l == 0 ? 1 : (l == 1 ? 0 : 2)) : 0;   // phi_theta, phi_v, phi_m
+          if (MULTI && l == 1 && skip_v) return;
           phi_head<D, H>(PT + A.t_off[fphi] + koff * A.t_sz[fphi], m, uh[j]);
         });
       }
@@ -311,6 +323,7 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
           constexpr int j = decltype(j_)::value;
           constexpr int l = L0 + j;
           constexpr int fphi = MULTI ? (l == 0 ? 1 : (l == 1 ? 0 : 2)) : 0;
+          if (MULTI && l == 1 && skip_v) return;
           f2 a1[H / 2], a2[H / 2];
           phi_tail<C::PHI_IN, H, D>(PT + A.t_off[fphi] + koff * A.t_sz[fphi], uh[j], xt, a1, a2);
 #pragma unroll
@@ -329,6 +342,11 @@ __global__ void __launch_bounds__(GNS_FWD_MAX_THREADS) gns_forward_kernel(GnsFwd
         if (false)
 #endif
           store_pairs_nt<H>(A.msg, ((((long long)k * A.G + g) * N + n) * C::NPHI + fphi) * C::HQ, lane, S[js]);
+        if (l == 1 && skip_v) {                             // (a generator bus keeps its voltage: main.py:184-186)
+          vth_new.x = s0.x;
+          if (!(use_plane && tsize == 1) || GNS_FWD_ROW_STORES) reinterpret_cast<float*>(row_ptr(A.state, wr, lane))[0] = s0.x;
+          return;
+        }
         f2 x[(C::LF_IN + 1) / 2];                           // [v theta | dp dq | m | sum h | deg]
         x[0] = f2{s0.x, s0.y}; x[1] = f2{s0.z, s0.w};
 #pragma unroll
