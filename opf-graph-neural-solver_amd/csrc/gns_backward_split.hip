@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(GNS_BWDS_PHYS_THREADS) gns_bwds_phys_kernel(Gn
   cip topo = (cip)A.topo;
   constexpr int pidx = 4;                                              // gns_part_index(16): the partition tables for 16 waves
   static_assert(GNS_BWDS_PHYS_WAVES == 16, "pidx");
-  const cip in_ptr = topo + topo[TH_IN_PTR], out_ptr = topo + topo[TH_OUT_PTR], q2p = topo + topo[TH_Q2P],
+  const cip in_ptr = topo + topo[TH_IN_PTR], out_ptr = topo + topo[TH_OUT_PTR], q2p = topo + topo[TH_Q2P], is_gen = topo + topo[TH_IS_GEN],
             incd_ptr = topo + topo[TH_INCD_PTR], incd = topo + topo[TH_INCD],
             part = topo + topo[TH_PART] + pidx * (GNS_MAXP + 1), epart = topo + topo[TH_EPART] + pidx * (GNS_MAXP + 1);
   const int n0 = part[wave], n1 = part[wave + 1];
@@ -135,11 +135,14 @@ __global__ void __launch_bounds__(GNS_BWDS_PHYS_THREADS) gns_bwds_phys_kernel(Gn
   // Two lines per iteration: the row / LDS loads of both are issued before either is evaluated (the phase waits on loads).
   {
     const cip erec = topo + topo[TH_EREC];
-    struct EdgeIn { f4 e1v, o0; float vs, ths, vt, tht, tha, thb, thc, thd, Fb, Tb; };
+    // (the adjoint of v on a generator bus feeds nothing - v is an input there and L_v never runs, main.py:184-186 - so the line phase
+    //  does not store it and the gather does not collect it)
+    struct EdgeIn { f4 e1v, o0; float vs, ths, vt, tht, tha, thb, thc, thd, Fb, Tb; bool gs, gt; };
     auto edge_load = [&](int p, EdgeIn& L) {
       // (s, t, a, b, q, c, d) of the line in one 32-byte scalar load (gns_topology.cpp)
       const gns_i8v r = *reinterpret_cast<const __attribute__((address_space(4))) gns_i8v*>(erec + 8 * p);
       const int s = r[0], t = r[1], ia = r[2], ib = r[3], q = r[4], ic = r[5], id = r[6];
+      L.gs = is_gen[s] != 0; L.gt = is_gen[t] != 0;
       L.e1v = *row_ptr(IN, row_ein + 3LL * p + 1, lane);                   // shift_e, y_s, tau_s, sh_s
       L.o0 = *row_ptr(IN, row_eout + q, lane);                              // y_t, tau_t, sh_t, b_t
       if (use_plane) {
@@ -189,7 +192,9 @@ __global__ void __launch_bounds__(GNS_BWDS_PHYS_THREADS) gns_bwds_phys_kernel(Gn
       const float dbar2 = Tb * vt * vt * o0.x * cD2 - Cb;
       dths -= Cb;
       // dtht == -dths bit for bit (Bb - Ab + Cb against Ab - Bb - Cb): plane 3 is not written, the gather negates plane 2
-      *slot_ptr(0, p) = dvs; *slot_ptr(1, p) = dvt; *slot_ptr(2, p) = dths;
+      if (!L.gs) *slot_ptr(0, p) = dvs;
+      if (!L.gt) *slot_ptr(1, p) = dvt;
+      *slot_ptr(2, p) = dths;
       *slot_ptr(4, p) = dbar; *slot_ptr(5, p) = dbar2;
     };
     for (int p = e0; p < e1; p += 2) {
@@ -209,12 +214,13 @@ __global__ void __launch_bounds__(GNS_BWDS_PHYS_THREADS) gns_bwds_phys_kernel(Gn
     float vbar = a0.x, thbar = a0.y;
     const float dpb = a0.z;
     const int p0 = in_ptr[n], p1 = in_ptr[n + 1], q0 = out_ptr[n], q1 = out_ptr[n + 1], i0 = incd_ptr[n], i1 = incd_ptr[n + 1];
+    const bool gen = is_gen[n] != 0;               // vbar of a generator bus is never read: its two planes are neither stored nor gathered
     {
       float ai[4], bi[4], ao[4], bo[4], ci[8];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { const int pp = min(p0 + j, max(p1 - 1, p0)); ai[j] = *slot_ptr(1, min(pp, E - 1)); bi[j] = -*slot_ptr(2, min(pp, E - 1)); }
+      for (int j = 0; j < 4; ++j) { const int pp = min(p0 + j, max(p1 - 1, p0)); ai[j] = gen ? 0.f : *slot_ptr(1, min(pp, E - 1)); bi[j] = -*slot_ptr(2, min(pp, E - 1)); }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { const int p = q2p[min(min(q0 + j, max(q1 - 1, q0)), E - 1)]; ao[j] = *slot_ptr(0, p); bo[j] = *slot_ptr(2, p); }
+      for (int j = 0; j < 4; ++j) { const int p = q2p[min(min(q0 + j, max(q1 - 1, q0)), E - 1)]; ao[j] = gen ? 0.f : *slot_ptr(0, p); bo[j] = *slot_ptr(2, p); }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int code = incd[min(min(i0 + j, max(i1 - 1, i0)), 4 * E - 1)];
@@ -231,14 +237,14 @@ __global__ void __launch_bounds__(GNS_BWDS_PHYS_THREADS) gns_bwds_phys_kernel(Gn
     for (int p = p0 + 4; p < p1; p += 4) {
       float a[4], bb[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { const int pp = min(p + j, p1 - 1); a[j] = *slot_ptr(1, pp); bb[j] = -*slot_ptr(2, pp); }
+      for (int j = 0; j < 4; ++j) { const int pp = min(p + j, p1 - 1); a[j] = gen ? 0.f : *slot_ptr(1, pp); bb[j] = -*slot_ptr(2, pp); }
 #pragma unroll
       for (int j = 0; j < 4; ++j) if (p + j < p1) { vbar += a[j]; thbar += bb[j]; }
     }
     for (int q = q0 + 4; q < q1; q += 4) {
       float a[4], bb[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { const int p = q2p[min(q + j, q1 - 1)]; a[j] = *slot_ptr(0, p); bb[j] = *slot_ptr(2, p); }
+      for (int j = 0; j < 4; ++j) { const int p = q2p[min(q + j, q1 - 1)]; a[j] = gen ? 0.f : *slot_ptr(0, p); bb[j] = *slot_ptr(2, p); }
 #pragma unroll
       for (int j = 0; j < 4; ++j) if (q + j < q1) { vbar += a[j]; thbar += bb[j]; }
     }
