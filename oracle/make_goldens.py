@@ -62,13 +62,14 @@ def _import_reference():
     return ref_main
 
 
-def run_case(ref, synth, name, case_nr, batch, K, d, h, multi, seed, load_scale=1.0, gamma=0.9):
+def run_case(ref, synth, name, case_nr, batch, K, d, h, multi, seed, load_scale=1.0, gamma=0.9, inputs=None):
+    """``inputs`` = (buses, lines, generators) replaces the synthetic case ``case_nr`` (the odd_* goldens: hand-made topologies)."""
     import warnings
     warnings.filterwarnings('ignore')
     torch.manual_seed(seed)
     model = ref.GNS(latent_dim=d, hidden_dim=h, K=K, gamma=gamma, multiple_phi=multi)
     B, L, G = ref.get_BLG()
-    buses, lines, gens = synth.synth_grids(case_nr, batch, seed=100 + seed, load_scale=load_scale)
+    buses, lines, gens = inputs if inputs is not None else synth.synth_grids(case_nr, batch, seed=100 + seed, load_scale=load_scale)
     trace = []
     orig_gac, orig_lpi = ref.global_active_compensation, ref.local_power_imbalance
 
@@ -270,6 +271,18 @@ def main():
     ]
     for c in cases:
         run_case(ref, synth, *c)
+    # shapes no case file has (tests/helpers.py::odd_topologies): parallel lines, a hub of in-degree 40, buses without lines,
+    # one-way chains, a generator on every bus / on one bus only / two on one bus.  name suffix, batch, K, d, multi, seed
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import helpers
+    topo = helpers.odd_topologies()
+    odd = [('pair', 3, 3, 20, True, 40), ('hub_all_gens', 2, 4, 10, False, 41), ('ring_isolated_dupgen', 3, 4, 20, True, 42),
+           ('chain_one_way', 2, 2, 20, False, 43), ('hub_indegree_40', 2, 3, 10, True, 44), ('random_40_one_gen', 2, 4, 20, True, 45),
+           ('random_33_many_gens', 2, 4, 20, False, 46)]
+    for tname, batch, K, d, multi, seed in odd:
+        n, f, t_, gb = topo[tname]
+        inputs = helpers.grids_on_topology(n, f, t_, gb, batch, seed)
+        run_case(ref, synth, f"odd_{tname}_b{batch}_K{K}_d{d}_{'multi' if multi else 'single'}", 0, batch, K, d, 10, multi, seed, inputs=inputs)
 
 
 if __name__ == '__main__':
