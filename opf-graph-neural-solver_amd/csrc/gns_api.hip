@@ -1,8 +1,10 @@
 // C-ABI entry points (include/gns_hip.h).  Host code only: validates, lays out the workspace and enqueues
 // kernels on the caller's stream.  No allocation, no synchronisation, no host<->device copies.
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
+#include <mutex>
 #include "gns_kernels.h"
 #include "gns_gridwg.h"
 
@@ -14,23 +16,14 @@ struct GnsTuning {
   int fwd_waves;     // GNS_FWD_WAVES: waves per workgroup of the lane mapping
   int fwd_plane;     // GNS_FWD_PLANE: LDS planes of the lane-mapping forward: 0 none (neighbour (v, theta) from HBM), 1 the (v, theta) plane, 2 (default) also (delta_p, delta_q) between the physics and lambda phases
   int dw_mfma;       // GNS_DW_MFMA=0: packed-FMA weight-gradient engine instead of the matrix pipe
-  int gw_ready;      // gns_gw_init_device() succeeded
   int train_mapping; // GNS_TRAIN_MAPPING: mapping of the training-mode forward + backward pair: 0 auto, 1 lane, 2 lds
   int bwd_variant;   // GNS_BWD_VARIANT: lane-per-grid backward: 1 wide half-wave records, 2 layer-wise + sub-record windows, 3 = 2 + background chains (one persistent kernel each); 4 split: one kernel sequence per reverse step (gns_backward_split.hip)
   int team;          // GNS_TEAM: workgroups per 64-grid group of the lane mapping when the batch leaves CUs idle: 0 auto, 1 none, 2, 4
-  int ncu;           // compute units of the device (teams must be resident all at once)
-  int split_ready;   // gns_bwds_init_device() succeeded
-  int fwd_ready;     // gns_fwd_init_device() succeeded (the lane-per-grid forward may use more than 64 KB of dynamic LDS)
   int bwds_mode;     // GNS_BWDS_MODE: sweep kernels per reverse step of the split backward: 0 one per family, 1 {L_m} {L_theta + L_v}, 2 all three families per bus in one kernel
   int bwds_chunks;   // GNS_BWDS_CHUNKS: bus chunks per 64-grid group of the split backward's sweeps (0 = auto: 12, 24 or 32)
 };
 GnsTuning make_tuning() {
-  GnsTuning t{0, 0, GNS_FWD_THREADS / 64, 2, 1, 0, 0, 4, 0, 0, 0, 0, 1, 0};
-  {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) t.ncu = n;
-    else (void)hipGetLastError();
-  }
+  GnsTuning t{0, 0, GNS_FWD_THREADS / 64, 2, 1, 0, 4, 0, 1, 0};
   if (const char* e = std::getenv("GNS_TEAM")) { const int v = std::atoi(e); if (v >= 0 && v <= GNS_MAX_TEAM) t.team = v; }
   if (const char* e = std::getenv("GNS_FWD_MAPPING")) t.fwd_mapping = !std::strcmp(e, "lane") ? 1 : (!std::strcmp(e, "lds") ? 2 : 0);
   if (const char* e = std::getenv("GNS_GW_PACK")) { const int p = std::atoi(e); if (p >= 1 && p <= 16) t.gw_pack = p; }
@@ -41,14 +34,47 @@ GnsTuning make_tuning() {
   if (const char* e = std::getenv("GNS_BWDS_MODE")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) t.bwds_mode = v; }
   if (const char* e = std::getenv("GNS_BWDS_CHUNKS")) { const int v = std::atoi(e); if (v == 0 || gns_part_index(v) >= 0) t.bwds_chunks = v; }
   if (const char* e = std::getenv("GNS_TRAIN_MAPPING")) t.train_mapping = !std::strcmp(e, "lane") ? 1 : (!std::strcmp(e, "lds") ? 2 : 0);
-  t.gw_ready = (gns_gw_init_device() == GNS_OK && gns_gw_backward_init_device() == GNS_OK) ? 1 : 0;
-  t.split_ready = gns_bwds_init_device() == GNS_OK ? 1 : 0;
-  t.fwd_ready = gns_fwd_init_device() == GNS_OK ? 1 : 0;
   return t;
 }
 GnsTuning& tuning() {
   static GnsTuning t = make_tuning();            // C++11: thread-safe one-time initialisation
   return t;
+}
+
+// ---- per-device state: kernel attributes (dynamic LDS beyond 64 KB is an opt-in per kernel AND device) and the CU count, set up
+// once per device at the first call that finds it current (one process per GPU is the normal deployment; a process that moves a
+// model to a second device gets that device initialised the same way).  Never runs inside a stream capture in practice: a capture
+// is preceded by eager warm-up calls on the same device.
+constexpr int GNS_MAX_DEVICES = 64;
+struct GnsDevice {
+  int ncu;           // compute units (teams must be resident all at once)
+  int gw_ready;      // gns_gw_init_device() and gns_gw_backward_init_device() succeeded
+  int split_ready;   // gns_bwds_init_device() succeeded
+  int fwd_ready;     // gns_fwd_init_device() succeeded (the lane-per-grid forward may use more than 64 KB of dynamic LDS)
+};
+const GnsDevice& device() {
+  static GnsDevice devs[GNS_MAX_DEVICES];
+  static std::atomic<int> done[GNS_MAX_DEVICES];
+  static std::mutex mu;
+  static const GnsDevice none{0, 0, 0, 0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return none; }     // no ROCm device: the entry points report it
+  if (dev < 0 || dev >= GNS_MAX_DEVICES) return none;
+  if (!done[dev].load(std::memory_order_acquire)) {
+    std::lock_guard<std::mutex> lock(mu);
+    if (!done[dev].load(std::memory_order_relaxed)) {
+      GnsDevice d{0, 0, 0, 0};
+      int n = 0;
+      if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) d.ncu = n;
+      else (void)hipGetLastError();
+      d.gw_ready = (gns_gw_init_device() == GNS_OK && gns_gw_backward_init_device() == GNS_OK) ? 1 : 0;
+      d.split_ready = gns_bwds_init_device() == GNS_OK ? 1 : 0;
+      d.fwd_ready = gns_fwd_init_device() == GNS_OK ? 1 : 0;
+      devs[dev] = d;
+      done[dev].store(1, std::memory_order_release);
+    }
+  }
+  return devs[dev];
 }
 }  // namespace
 
@@ -120,14 +146,14 @@ static int lane_team(int64_t Bt) {
   const GnsTuning& T = tuning();
   const int64_t groups = (Bt + GNS_LANES - 1) / GNS_LANES;
   if (groups > GNS_TEAM_MAX_GROUPS) return 1;
-  const int ncu = T.ncu < GNS_BWD_MAX_WG ? T.ncu : GNS_BWD_MAX_WG;
+  const int ncu = device().ncu < GNS_BWD_MAX_WG ? device().ncu : GNS_BWD_MAX_WG;
   return gns_team_size(groups, ncu, T.team);
 }
 
 // The split backward (bwd_variant 4) runs the three-phi models on the matrix-pipe engine; everything else keeps the persistent kernel.
 static bool use_split_backward(const gns_config* c) {
   const GnsTuning& T = tuning();
-  return T.bwd_variant == 4 && T.split_ready && T.dw_mfma && gns_bwds_supported(c->latent_dim, c->hidden_dim, c->multiple_phi);
+  return T.bwd_variant == 4 && device().split_ready && T.dw_mfma && gns_bwds_supported(c->latent_dim, c->hidden_dim, c->multiple_phi);
 }
 
 // Which mapping runs a training-mode forward and its backward.  Evaluated identically by gns_forward and gns_backward:
@@ -135,7 +161,7 @@ static bool use_split_backward(const gns_config* c) {
 static int gw_train_pack(const gns_config* c, int64_t Bt) {
   const GnsTuning& T = tuning();
   const int P = T.gw_pack > 0 ? T.gw_pack : 1;
-  if (!T.gw_ready || T.train_mapping == 1) return 0;
+  if (!device().gw_ready || T.train_mapping == 1) return 0;
   if (!gns_gw_supported(c->n_bus, c->n_line, c->latent_dim, c->hidden_dim, c->multiple_phi, P)) return 0;
   if (!gns_gw_backward_supported(c->n_bus, c->n_line, c->latent_dim, c->hidden_dim, c->multiple_phi, P)) return 0;
   if (T.train_mapping == 2) return P;
@@ -157,7 +183,7 @@ static int gw_eval_pack(const gns_config* c) {
     const int wpg = ((N > E ? N : E) + 63) / 64;
     for (int q = 2; q * wpg <= 12; ++q) if (gns_gw_supported(N, E, c->latent_dim, c->hidden_dim, c->multiple_phi, q)) P = q;
   }
-  const bool can = T.gw_ready && gns_gw_supported(N, E, c->latent_dim, c->hidden_dim, c->multiple_phi, P);
+  const bool can = device().gw_ready && gns_gw_supported(N, E, c->latent_dim, c->hidden_dim, c->multiple_phi, P);
   const bool want = T.fwd_mapping == 2 || (T.fwd_mapping == 0 && N >= 48);
   return (can && want) ? P : 0;
 }
@@ -253,9 +279,9 @@ extern "C" int gns_workspace_bytes(const gns_config* cfg, int64_t Bt, int save_s
     GnsBwdLayout B;
     gns_bwd_layout(cfg->n_bus, cfg->n_line, cfg->latent_dim, cfg->hidden_dim, cfg->K, cfg->multiple_phi, Bt, lane_team(Bt), &B);
     *bwd_bytes = B.total;
-    if (tuning().split_ready && gns_bwds_supported(cfg->latent_dim, cfg->hidden_dim, cfg->multiple_phi)) {   // either variant may be asked for later
+    if (device().split_ready && gns_bwds_supported(cfg->latent_dim, cfg->hidden_dim, cfg->multiple_phi)) {   // either variant may be asked for later
       GnsBwdsLayout S;
-      gns_bwds_layout(cfg->n_bus, cfg->n_line, cfg->latent_dim, cfg->hidden_dim, cfg->K, cfg->multiple_phi, Bt, tuning().ncu, tuning().bwds_chunks, &S);
+      gns_bwds_layout(cfg->n_bus, cfg->n_line, cfg->latent_dim, cfg->hidden_dim, cfg->K, cfg->multiple_phi, Bt, device().ncu, tuning().bwds_chunks, &S);
       if (S.total > *bwd_bytes) *bwd_bytes = S.total;
     }
   }
@@ -405,7 +431,7 @@ extern "C" int gns_forward(const gns_config* cfg, const void* topo_dev, const fl
   while (waves * A.team > GNS_MAXP) waves /= 2;
   A.part_idx = gns_part_index(waves * A.team);
   auto pick_planes = [&]() {
-    A.plane = (T.fwd_ready && gns_fwd_plane_fits(N, A.team) && T.fwd_plane) ? 1 : 0;
+    A.plane = (device().fwd_ready && gns_fwd_plane_fits(N, A.team) && T.fwd_plane) ? 1 : 0;
     if (A.plane && gns_fwd_plane2_fits(N, A.team) && T.fwd_plane == 2) A.plane = 2;
   };
   pick_planes();
@@ -413,7 +439,7 @@ extern "C" int gns_forward(const gns_config* cfg, const void* topo_dev, const fl
     // every workgroup of every team must be resident at once: the kernel's own occupancy at this launch configuration says
     // how many a CU holds (not just the CU count); a configuration that does not fit runs one workgroup per group instead
     const int per_cu = gns_fwd_blocks_per_cu(d, h, cfg->multiple_phi, A, waves * 64);
-    if ((long long)per_cu * T.ncu < A.G * A.team) {
+    if ((long long)per_cu * device().ncu < A.G * A.team) {
       A.team = 1;
       waves = T.fwd_waves;
       A.part_idx = gns_part_index(waves);
@@ -474,7 +500,7 @@ extern "C" int gns_backward(const gns_config* cfg, const void* topo_dev, const f
   gns_fwd_layout(N, E, d, h, K, cfg->multiple_phi, Bt, 1, &L);
   if (use_split_backward(cfg)) {
     GnsBwdsLayout S;
-    gns_bwds_layout(N, E, d, h, K, cfg->multiple_phi, Bt, tuning().ncu, tuning().bwds_chunks, &S);
+    gns_bwds_layout(N, E, d, h, K, cfg->multiple_phi, Bt, device().ncu, tuning().bwds_chunks, &S);
     if (fwd_workspace_bytes < L.total || bwd_workspace_bytes < S.total) return GNS_ESIZE;
     GnsFamilies fam; gns_families(d, h, K, cfg->multiple_phi, &fam);
     hipStream_t st = (hipStream_t)stream;
