@@ -30,7 +30,7 @@ extern "C" {
 enum {
   GNS_OK = 0,
   GNS_EINVAL = 1,      /* null pointer / non-positive size / malformed config            */
-  GNS_EUNSUPPORTED = 2,/* (latent_dim, hidden_dim) pair has no compiled kernel           */
+  GNS_EUNSUPPORTED = 2,/* no compiled kernel holds this (latent_dim, hidden_dim), or K > 64 */
   GNS_ETOPOLOGY = 3,   /* bus id out of range, or a bus id that is not a valid line index
                           (the reference gathers per-line arrays with bus ids, main.py:41)  */
   GNS_ESIZE = 4,       /* caller-provided buffer too small                               */
@@ -56,7 +56,9 @@ const char* gns_version(void);
  * params buffer (GNS/main.py:113-134).  */
 int gns_param_count(const gns_config* cfg, int64_t* count);
 
-/* 1 if a fused kernel is compiled for this (latent_dim, hidden_dim, multiple_phi), else 0. */
+/* 1 if a compiled kernel holds this model, else 0.  Kernels are compiled for (latent_dim, hidden_dim) = (20, 10) and (10, 10), both
+ * phi modes; a narrower model (any latent_dim <= 20, hidden_dim <= 10, e.g. the "less hidden dim" of main.py:215) runs on the next wider
+ * pair zero-padded - same outputs, same gradients, delivered in the MODEL's flat layout (gns_param_count floats). */
 int gns_config_supported(const gns_config* cfg);
 
 /* Host-side topology preparation (replaces the per-call index construction of main.py:35-36,85-86,144,153):

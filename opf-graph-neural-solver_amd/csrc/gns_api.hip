@@ -111,11 +111,20 @@ extern "C" int gns_get_option(const char* name, int* value) {
   return GNS_OK;
 }
 
-static bool dims_supported(int d, int h) {
-#define GNS_CASE(DD, HH) if (d == DD && h == HH) return true;
+// The compiled (latent_dim, hidden_dim) pair a model runs on: the smallest one that holds it.  A narrower model runs zero-padded
+// (gns_common.h, GnsFamilies): same function, same gradients; only gns_pack_params / gns_unfold know the difference.
+static bool kernel_dims(int d, int h, int* dk, int* hk) {
+  bool found = false;
+#define GNS_CASE(DD, HH) if (d <= DD && h <= HH && (!found || DD * HH < *dk * *hk)) { *dk = DD; *hk = HH; found = true; }
   GNS_FOR_EACH_DIMS(GNS_CASE)
 #undef GNS_CASE
-  return false;
+  return found;
+}
+static bool dims_supported(int d, int h) { int dk, hk; return kernel_dims(d, h, &dk, &hk); }
+// cfg with the kernel's dims in place of the model's (everything but the flat parameter layout is sized by these)
+static bool kernel_config(const gns_config* model, gns_config* k) {
+  *k = *model;
+  return kernel_dims(model->latent_dim, model->hidden_dim, &k->latent_dim, &k->hidden_dim);
 }
 
 static int check_cfg(const gns_config* c) {
@@ -260,6 +269,9 @@ extern "C" int gns_workspace_bytes(const gns_config* cfg, int64_t Bt, int save_s
   int rc = check_cfg(cfg);
   if (rc != GNS_OK) return rc;
   if (Bt <= 0) return GNS_EINVAL;
+  const gns_config* model = cfg; gns_config kcfg_;
+  if (!kernel_config(model, &kcfg_)) return GNS_EUNSUPPORTED;
+  cfg = &kcfg_; (void)model;
   GnsFwdLayout L;
   gns_fwd_layout(cfg->n_bus, cfg->n_line, cfg->latent_dim, cfg->hidden_dim, cfg->K, cfg->multiple_phi, Bt, save_state, &L);
   const int P = save_state ? gw_train_pack(cfg, Bt) : 0;
@@ -290,6 +302,9 @@ extern "C" int gns_workspace_bytes(const gns_config* cfg, int64_t Bt, int save_s
 
 extern "C" int gns_uses_packed_inputs(const gns_config* cfg, int64_t Bt, int save_state) {
   if (check_cfg(cfg) != GNS_OK || Bt <= 0) return 0;
+  const gns_config* model = cfg; gns_config kcfg_;
+  if (!kernel_config(model, &kcfg_)) return 0;
+  cfg = &kcfg_; (void)model;
   return (save_state ? gw_train_pack(cfg, Bt) : gw_eval_pack(cfg)) > 0 ? 0 : 1;
 }
 
@@ -304,6 +319,9 @@ extern "C" int gns_team_status_offset(const gns_config* cfg, int64_t Bt, int sav
   int rc = check_cfg(cfg);
   if (rc != GNS_OK) return rc;
   if (!offset || Bt <= 0) return GNS_EINVAL;
+  const gns_config* model = cfg; gns_config kcfg_;
+  if (!kernel_config(model, &kcfg_)) return GNS_EUNSUPPORTED;
+  cfg = &kcfg_; (void)model;
   *offset = (size_t)-1;
   if (lane_team(Bt) <= 1) return GNS_OK;
   if ((save_state ? gw_train_pack(cfg, Bt) : gw_eval_pack(cfg)) > 0) return GNS_OK;          // the grid-per-workgroup kernels have no teams
@@ -318,6 +336,9 @@ extern "C" int gns_team_status(const gns_config* cfg, int64_t Bt, const void* fw
   int rc = check_cfg(cfg);
   if (rc != GNS_OK) return rc;
   if (!status || !fwd_workspace || Bt <= 0) return GNS_EINVAL;
+  const gns_config* model = cfg; gns_config kcfg_;
+  if (!kernel_config(model, &kcfg_)) return GNS_EUNSUPPORTED;
+  cfg = &kcfg_; (void)model;
   *status = 0;
   if (lane_team(Bt) <= 1) return GNS_OK;
   if ((save_state ? gw_train_pack(cfg, Bt) : gw_eval_pack(cfg)) > 0) return GNS_OK;          // the grid-per-workgroup kernels have no teams
@@ -359,9 +380,11 @@ extern "C" int gns_forward(const gns_config* cfg, const void* topo_dev, const fl
   if (rc != GNS_OK) return rc;
   if (!topo_dev || !params || !buses || !lines || !generators || !v || !theta || !total_loss || !last_loss || !workspace || Bt <= 0)
     return GNS_EINVAL;
-  if (!dims_supported(cfg->latent_dim, cfg->hidden_dim) || cfg->K > GNS_MAX_K) return GNS_EUNSUPPORTED;
+  const gns_config* model = cfg; gns_config kcfg_;
+  if (!kernel_config(model, &kcfg_) || cfg->K > GNS_MAX_K) return GNS_EUNSUPPORTED;
+  cfg = &kcfg_;                          // the kernel's dims from here on; the model's only lay out the flat parameters
   const int N = cfg->n_bus, E = cfg->n_line, Gn = cfg->n_gen, K = cfg->K, d = cfg->latent_dim, h = cfg->hidden_dim;
-  GnsFamilies fam; gns_families(d, h, K, cfg->multiple_phi, &fam);
+  GnsFamilies fam; gns_families_padded(model->latent_dim, model->hidden_dim, d, h, K, cfg->multiple_phi, &fam);
   hipStream_t st = (hipStream_t)stream;
   char* ws = (char*)workspace;
   const GnsTuning& T = tuning();
@@ -462,13 +485,15 @@ extern "C" int gns_backward(const gns_config* cfg, const void* topo_dev, const f
   int rc = check_cfg(cfg);
   if (rc != GNS_OK) return rc;
   if (!topo_dev || !params || !fwd_workspace || !grad_params || !bwd_workspace || Bt <= 0) return GNS_EINVAL;
-  if (!dims_supported(cfg->latent_dim, cfg->hidden_dim) || cfg->K > GNS_MAX_K) return GNS_EUNSUPPORTED;
+  const gns_config* model = cfg; gns_config kcfg_;
+  if (!kernel_config(model, &kcfg_) || cfg->K > GNS_MAX_K) return GNS_EUNSUPPORTED;
+  cfg = &kcfg_;                          // the kernel's dims from here on; the model's only lay out the flat parameters and their gradient
   const int N = cfg->n_bus, E = cfg->n_line, K = cfg->K, d = cfg->latent_dim, h = cfg->hidden_dim;
   if (const int TP = gw_train_pack(cfg, Bt)) {                            // the pair of the grid-per-workgroup training forward
     if (!buses || !lines || !generators) return GNS_EINVAL;
     const GwTrainLayout GL = gw_train_layout(cfg, Bt, TP);
     if (fwd_workspace_bytes < GL.fwd_total || bwd_workspace_bytes < GL.bwd_total) return GNS_ESIZE;
-    GnsFamilies fam; gns_families(d, h, K, cfg->multiple_phi, &fam);
+    GnsFamilies fam; gns_families_padded(model->latent_dim, model->hidden_dim, d, h, K, cfg->multiple_phi, &fam);
     hipStream_t st = (hipStream_t)stream;
     const char* fw = (const char*)fwd_workspace;
     char* bw = (char*)bwd_workspace;
@@ -502,7 +527,7 @@ extern "C" int gns_backward(const gns_config* cfg, const void* topo_dev, const f
     GnsBwdsLayout S;
     gns_bwds_layout(N, E, d, h, K, cfg->multiple_phi, Bt, device().ncu, tuning().bwds_chunks, &S);
     if (fwd_workspace_bytes < L.total || bwd_workspace_bytes < S.total) return GNS_ESIZE;
-    GnsFamilies fam; gns_families(d, h, K, cfg->multiple_phi, &fam);
+    GnsFamilies fam; gns_families_padded(model->latent_dim, model->hidden_dim, d, h, K, cfg->multiple_phi, &fam);
     hipStream_t st = (hipStream_t)stream;
     const char* fw = (const char*)fwd_workspace;
     char* bw = (char*)bwd_workspace;
@@ -540,7 +565,7 @@ extern "C" int gns_backward(const gns_config* cfg, const void* topo_dev, const f
   const int team = lane_team(Bt);
   gns_bwd_layout(N, E, d, h, K, cfg->multiple_phi, Bt, team, &B);
   if (fwd_workspace_bytes < L.total || bwd_workspace_bytes < B.total) return GNS_ESIZE;
-  GnsFamilies fam; gns_families(d, h, K, cfg->multiple_phi, &fam);
+  GnsFamilies fam; gns_families_padded(model->latent_dim, model->hidden_dim, d, h, K, cfg->multiple_phi, &fam);
   hipStream_t st = (hipStream_t)stream;
   const char* fw = (const char*)fwd_workspace;
   char* bw = (char*)bwd_workspace;

@@ -942,48 +942,71 @@ __global__ void gns_reduce_stage2(const float* __restrict__ part, float* __restr
 // One block per (family, k); a phi block also collects dW4/db4 from every L family that reads it, in a fixed order.
 __global__ void gns_unfold_kernel(const float* __restrict__ gf, const float* __restrict__ flat, float* __restrict__ grad,
                                   GnsFamilies fam, int K, int D, int H) {
+  // D, H = the kernel's dims (layout of the folded gradient gf); Dr, Hr <= them = the model's (layout of flat / grad): a narrower
+  // model ran zero-padded (gns_common.h, GnsFamilies) and the gradient of its padding is dropped here
   const int blk = blockIdx.x, f = blk / K, k = blk % K;
   const bool is_phi = f < fam.nphi;
-  const int IN = fam.in[f], OUT = fam.out[f];
-  const int HEAD = 4 + D, INF = HEAD + H + 1;
+  const int Dr = fam.dr, Hr = fam.hr;
+  const int IN = fam.in[f], OUT = fam.out[f];                     // the model's
+  const int HEAD = 4 + D, INF = HEAD + H + 1, HEADr = 4 + Dr;
   const float* g = gf + fam.g_off[f] + (int64_t)k * fam.g_sz[f];
   float* dst = grad + fam.flat_off[f] + (int64_t)k * fam.flat_sz[f];
   if (is_phi) {
-    const int n12 = IN * H + H + H * H + H;                       // W1 b1 W2 b2 sit at the same offsets in both layouts
-    for (int e = threadIdx.x; e < n12; e += blockDim.x) dst[e] += g[e];
-    float* dW4 = dst + n12;                                       // [OUT][H]
-    float* db4 = dW4 + OUT * H;
-    for (int e = threadIdx.x; e < OUT * H + OUT; e += blockDim.x) {
+    const int INk = D + 5;
+    const int gb1 = INk * H, gW2 = gb1 + H, gb2 = gW2 + H * H;    // folded gradient: W1[H][INk] b1[H] W2[H][H] b2[H]
+    const int oW1 = IN * Hr, ob1 = oW1 + Hr, oW2 = ob1 + Hr * Hr, n12 = oW2 + Hr;
+    for (int e = threadIdx.x; e < n12; e += blockDim.x) {
+      float v;
+      if (e < oW1) { const int c = e / IN, i = e % IN; v = g[c * INk + (i < Dr ? i : D + (i - Dr))]; }
+      else if (e < ob1) v = g[gb1 + (e - oW1)];
+      else if (e < oW2) { const int q = e - ob1; v = g[gW2 + (q / Hr) * H + (q % Hr)]; }
+      else v = g[gb2 + (e - oW2)];
+      dst[e] += v;
+    }
+    float* dW4 = dst + n12;                                       // [OUT][Hr]
+    float* db4 = dW4 + OUT * Hr;
+    for (int e = threadIdx.x; e < OUT * Hr + OUT; e += blockDim.x) {
       float acc = 0.f;
       for (int lf = fam.nphi; lf < fam.nfam; ++lf) {
         if (fam.phi_of[lf] != f) continue;
         const float* gl = gf + fam.g_off[lf] + (int64_t)k * fam.g_sz[lf];             // dW1'[H][INF]
-        const float* Wl = flat + fam.flat_off[lf] + (int64_t)k * fam.flat_sz[lf];     // W1L [H][L_IN]
+        const float* Wl = flat + fam.flat_off[lf] + (int64_t)k * fam.flat_sz[lf];     // W1L [Hr][L_IN]
         const int LIN = fam.in[lf];
-        if (e < OUT * H) { const int q = e / H, j = e % H; for (int c = 0; c < H; ++c) acc += Wl[c * LIN + HEAD + q] * gl[c * INF + HEAD + j]; }
-        else { const int q = e - OUT * H; for (int c = 0; c < H; ++c) acc += Wl[c * LIN + HEAD + q] * gl[c * INF + HEAD + H]; }
+        if (e < OUT * Hr) { const int q = e / Hr, j = e % Hr; for (int c = 0; c < Hr; ++c) acc += Wl[c * LIN + HEADr + q] * gl[c * INF + HEAD + j]; }
+        else { const int q = e - OUT * Hr; for (int c = 0; c < Hr; ++c) acc += Wl[c * LIN + HEADr + q] * gl[c * INF + HEAD + H]; }
       }
-      if (e < OUT * H) dW4[e] += acc; else db4[e - OUT * H] += acc;
+      if (e < OUT * Hr) dW4[e] += acc; else db4[e - OUT * Hr] += acc;
     }
     return;
   }
   const int fp = fam.phi_of[f], PO = fam.out[fp];
   const float* ps = flat + fam.flat_off[fp] + (int64_t)k * fam.flat_sz[fp];
-  const float* pW4 = ps + fam.in[fp] * H + H + H * H + H;
-  const float* pb4 = pW4 + PO * H;
-  for (int e = threadIdx.x; e < H * IN; e += blockDim.x) {        // dW1L [H][IN]
+  const float* pW4 = ps + fam.in[fp] * Hr + Hr + Hr * Hr + Hr;
+  const float* pb4 = pW4 + PO * Hr;
+  for (int e = threadIdx.x; e < Hr * IN; e += blockDim.x) {       // dW1L [Hr][IN]
     const int c = e / IN, i = e % IN;
     float v = 0.f;
-    if (i < HEAD) v = g[c * INF + i];
-    else if (i - HEAD < PO) {
-      const int q = i - HEAD;
-      for (int j = 0; j < H; ++j) v += g[c * INF + HEAD + j] * pW4[q * H + j];
+    if (i < HEADr) v = g[c * INF + i];                            // (4 + latent index: the same column in both layouts)
+    else if (i - HEADr < PO) {
+      const int q = i - HEADr;
+      for (int j = 0; j < Hr; ++j) v += g[c * INF + HEAD + j] * pW4[q * Hr + j];
       v += g[c * INF + HEAD + H] * pb4[q];
     }                                                             // single phi: columns 4+d+1.. multiply zeros -> gradient 0
     dst[e] += v;
   }
-  const int rest = H + H * H + H + OUT * H + OUT;                 // b1 W2 b2 W4 b4
-  for (int e = threadIdx.x; e < rest; e += blockDim.x) dst[H * IN + e] += g[H * INF + e];
+  // b1 W2 b2 W4 b4: folded gradient [H] [H][H] [H] [OUTk][H] [OUTk] behind W1'[H][INF]
+  const int OUTk = fam.outk[f];
+  const int gb1 = H * INF, gW2 = gb1 + H, gb2 = gW2 + H * H, gW4 = gb2 + H, gb4 = gW4 + OUTk * H;
+  const int ob1 = Hr * IN, oW2 = ob1 + Hr, ob2 = oW2 + Hr * Hr, oW4 = ob2 + Hr, ob4 = oW4 + OUT * Hr, oend = ob4 + OUT;
+  for (int e = ob1 + threadIdx.x; e < oend; e += blockDim.x) {
+    float v;
+    if (e < oW2) v = g[gb1 + (e - ob1)];
+    else if (e < ob2) { const int q = e - oW2; v = g[gW2 + (q / Hr) * H + (q % Hr)]; }
+    else if (e < oW4) v = g[gb2 + (e - ob2)];
+    else if (e < ob4) { const int q = e - oW4; v = g[gW4 + (q / Hr) * H + (q % Hr)]; }
+    else v = g[gb4 + (e - ob4)];
+    dst[e] += v;
+  }
 }
 
 template <int D, int H, bool MULTI, bool MFMA, int VAR>

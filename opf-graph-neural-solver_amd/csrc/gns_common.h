@@ -119,34 +119,45 @@ GNS_HD static inline int64_t gns_n_block(bool is_phi, int d, int h, int out) {
 struct GnsFamilies {   // per network family (phi*, L_theta, L_v, L_m) in state_dict order
   int nfam;            // 4 (single phi) or 6
   int nphi;            // 1 or 3
-  int in[6], out[6];   // UNFOLDED shapes (the flat / state_dict layout)
+  int in[6], out[6];   // UNFOLDED shapes of the MODEL (the flat / state_dict layout)
   int phi_of[6];       // for an L family: the phi family whose message sum it reads (main.py:165-171)
   int64_t flat_off[6], t_off[6], n_off[6], g_off[6];   // offset of block k=0 of the family (g: folded-gradient slab layout)
   int64_t flat_sz[6], t_sz[6], n_sz[6], g_sz[6];       // per-k block size
   int64_t flat_total, t_total, n_total, g_total;
+  // A model narrower than a compiled kernel runs on it ZERO-PADDED: hidden units with zero weights and biases stay 0 through
+  // LeakyReLU and feed nothing, latent components beyond the model's start at 0 (main.py:141) and are updated by zero rows, and every
+  // added term of every sum is an exact +0 - the same function and gradients, bit for bit what the kernel computes for the padded
+  // model.  dr, hr = the model's (latent_dim, hidden_dim): the flat layout; dk, hk >= them = the kernel's: the t / n / g layouts.
+  int dr, hr, dk, hk;
+  int outk[6];         // output width of the family in kernel dims (dk for phi* of three-phi models and L_m, else 1)
 };
 
-static inline void gns_families(int d, int h, int K, int multi, GnsFamilies* f) {
+static inline void gns_families_padded(int dr, int hr, int dk, int hk, int K, int multi, GnsFamilies* f) {
   f->nfam = multi ? 6 : 4;
   f->nphi = multi ? 3 : 1;
+  f->dr = dr; f->hr = hr; f->dk = dk; f->hk = hk;
   int64_t fo = 0, to = 0, no = 0, go = 0;
   for (int i = 0; i < f->nfam; ++i) {
     bool is_phi = i < f->nphi;
-    f->in[i] = is_phi ? d + 5 : 4 + 2 * d;
-    f->out[i] = is_phi ? (multi ? d : 1) : (i == f->nfam - 1 ? d : 1);
+    const bool wide_out = is_phi ? multi != 0 : i == f->nfam - 1;
+    f->in[i] = is_phi ? dr + 5 : 4 + 2 * dr;
+    f->out[i] = wide_out ? dr : 1;
+    f->outk[i] = wide_out ? dk : 1;
+    const int ink = is_phi ? dk + 5 : 4 + 2 * dk;
     // L_theta reads phi_theta, L_v reads phi_v, L_m reads phi_m; registration order is phi_v, phi_theta, phi_m (main.py:113-116)
     f->phi_of[i] = is_phi ? -1 : (multi ? (i == 3 ? 1 : (i == 4 ? 0 : 2)) : 0);
-    f->flat_sz[i] = gns_flat_block(f->in[i], h, f->out[i]);
-    f->t_sz[i] = gns_t_block(is_phi, d, h, f->out[i]);
-    f->n_sz[i] = gns_n_block(is_phi, d, h, f->out[i]);
+    f->flat_sz[i] = gns_flat_block(f->in[i], hr, f->out[i]);
+    f->t_sz[i] = gns_t_block(is_phi, dk, hk, f->outk[i]);
+    f->n_sz[i] = gns_n_block(is_phi, dk, hk, f->outk[i]);
     // gradient of the folded block: phi' W1[h][in] b1 W2 b2 ; L' W1'[h][in'] b1 W2 b2 W4[out][h] b4
-    f->g_sz[i] = is_phi ? (int64_t)f->in[i] * h + h + (int64_t)h * h + h
-                        : (int64_t)gns_lin(d, h) * h + h + (int64_t)h * h + h + (int64_t)f->out[i] * h + f->out[i];
+    f->g_sz[i] = is_phi ? (int64_t)ink * hk + hk + (int64_t)hk * hk + hk
+                        : (int64_t)gns_lin(dk, hk) * hk + hk + (int64_t)hk * hk + hk + (int64_t)f->outk[i] * hk + f->outk[i];
     f->flat_off[i] = fo; f->t_off[i] = to; f->n_off[i] = no; f->g_off[i] = go;
     fo += f->flat_sz[i] * K; to += f->t_sz[i] * K; no += f->n_sz[i] * K; go += f->g_sz[i] * K;
   }
   f->flat_total = fo; f->g_total = go; f->t_total = to + 64; f->n_total = no + 64;   // +64: the 16-float chunk loader may read past the end
 }
+static inline void gns_families(int d, int h, int K, int multi, GnsFamilies* f) { gns_families_padded(d, h, d, h, K, multi, f); }
 
 // ---- forward workspace layout (byte offsets, 256-B aligned) -----------------------------------------
 struct GnsFwdLayout {

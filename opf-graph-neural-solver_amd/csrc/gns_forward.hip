@@ -12,66 +12,81 @@
 // ------------------------------------------------------------------------------------------------
 __global__ void gns_pack_params_kernel(const float* __restrict__ flat, float* __restrict__ pt, float* __restrict__ pn,
                                        GnsFamilies fam, int K, int D, int H) {
+  // D, H = the kernel's dims (destination layouts); Dr, Hr <= them = the model's (source layout).  Positions the model does not
+  // have are written as zeros (gns_common.h, GnsFamilies: a narrower model runs zero-padded).
   const int blk = blockIdx.x;            // (family, k)
   const int f = blk / K, k = blk % K;
   const bool is_phi = f < fam.nphi;
-  const int IN = fam.in[f], OUT = fam.out[f], OUTP = OUT + (OUT & 1);
+  const int Dr = fam.dr, Hr = fam.hr;
+  const int INr = fam.in[f], OUTr = fam.out[f];
+  const int OUT = fam.outk[f], OUTP = OUT + (OUT & 1);
   const float* src = flat + fam.flat_off[f] + (int64_t)k * fam.flat_sz[f];
-  const int sW1 = 0, sb1 = IN * H, sW2 = sb1 + H, sb2 = sW2 + H * H, sW4 = sb2 + H, sb4 = sW4 + OUT * H;
+  const int sW1 = 0, sb1 = INr * Hr, sW2 = sb1 + Hr, sb2 = sW2 + Hr * Hr, sW4 = sb2 + Hr, sb4 = sW4 + OUTr * Hr;
+  auto W2r = [&](int j, int i) -> float { return (j < Hr && i < Hr) ? src[sW2 + j * Hr + i] : 0.f; };      // linear2.weight[j][i]
+  auto b1r = [&](int j) -> float { return j < Hr ? src[sb1 + j] : 0.f; };
+  auto b2r = [&](int j) -> float { return j < Hr ? src[sb2 + j] : 0.f; };
   float* t = pt + fam.t_off[f] + (int64_t)k * fam.t_sz[f];
   float* n = pn + fam.n_off[f] + (int64_t)k * fam.n_sz[f];
   if (is_phi) {
-    const int INP = IN + (IN & 1);
+    const int IN = D + 5, INP = IN + (IN & 1);
+    // input i of the kernel's phi': latent component i (< D) or line parameter i - D; -1 = a padded latent component
+    auto W1r = [&](int j, int i) -> float {                       // linear1.weight[j][i] in kernel indices
+      if (j >= Hr) return 0.f;
+      const int ir = i < D ? (i < Dr ? i : -1) : Dr + (i - D);
+      return ir >= 0 ? src[sW1 + j * INr + ir] : 0.f;
+    };
     const int ob1 = IN * H, oW2 = ob1 + H, ob2 = oW2 + H * H, tt = ob2 + H;
     for (int e = threadIdx.x; e < (int)fam.t_sz[f]; e += blockDim.x) {
       float v = 0.f;
-      if (e < ob1) { int i = e / H, j = e % H; v = src[sW1 + j * IN + i]; }
-      else if (e < oW2) v = src[sb1 + (e - ob1)];
-      else if (e < ob2) { int q = e - oW2, i = q / H, j = q % H; v = src[sW2 + j * H + i]; }
-      else if (e < tt) v = src[sb2 + (e - ob2)];
+      if (e < ob1) { int i = e / H, j = e % H; v = W1r(j, i); }
+      else if (e < oW2) v = b1r(e - ob1);
+      else if (e < ob2) { int q = e - oW2, i = q / H, j = q % H; v = W2r(j, i); }
+      else if (e < tt) v = b2r(e - ob2);
       t[e] = v;
     }
     const int nW1 = H * H, nt = nW1 + H * INP;
     for (int e = threadIdx.x; e < (int)fam.n_sz[f]; e += blockDim.x) {
       float v = 0.f;
-      if (e < nW1) v = src[sW2 + e];
-      else if (e < nt) { int q = e - nW1, j = q / INP, i = q % INP; v = i < IN ? src[sW1 + j * IN + i] : 0.f; }
-      else { int q = e - nt, g = q / (4 * H), j = (q % (4 * H)) / 4, i = 4 * g + (q & 3); v = (g < (D + 3) / 4 && i < D) ? src[sW1 + j * IN + i] : 0.f; }   // W1x: latent columns
+      if (e < nW1) v = W2r(e / H, e % H);
+      else if (e < nt) { int q = e - nW1, j = q / INP, i = q % INP; v = i < IN ? W1r(j, i) : 0.f; }
+      else { int q = e - nt, g = q / (4 * H), j = (q % (4 * H)) / 4, i = 4 * g + (q & 3); v = (g < (D + 3) / 4 && i < D) ? W1r(j, i) : 0.f; }   // W1x: latent columns
       n[e] = v;
     }
     return;
   }
   // L family: input of the folded first layer = [v theta dp dq | m (D) | sum_e h_e (H) | deg]
   const int fp = fam.phi_of[f];
-  const int PO = fam.out[fp];                                   // phi output width: D (multi) or 1
+  const int PO = fam.out[fp];                                   // phi output width of the model: Dr (multi) or 1
   const float* ps = flat + fam.flat_off[fp] + (int64_t)k * fam.flat_sz[fp];
-  const int PIN = fam.in[fp];
-  const float* pW4 = ps + PIN * H + H + H * H + H;              // phi linear4.weight [PO][H]
-  const float* pb4 = pW4 + PO * H;                              // phi linear4.bias  [PO]
-  const int HEAD = 4 + D, INF = HEAD + H + 1, INFP = INF + (INF & 1);
-  auto w1f = [&](int c, int i) -> float {                       // folded first-layer weight W1'[c][i]
-    if (i < HEAD) return src[sW1 + c * IN + i];
+  const int PINr = fam.in[fp];
+  const float* pW4 = ps + PINr * Hr + Hr + Hr * Hr + Hr;        // phi linear4.weight [PO][Hr]
+  const float* pb4 = pW4 + PO * Hr;                             // phi linear4.bias  [PO]
+  const int HEAD = 4 + D, HEADr = 4 + Dr, INF = HEAD + H + 1, INFP = INF + (INF & 1);
+  auto w1f = [&](int c, int i) -> float {                       // folded first-layer weight W1'[c][i] in kernel indices
+    if (c >= Hr) return 0.f;
+    if (i < HEAD) return (i < 4 || i - 4 < Dr) ? src[sW1 + c * INr + i] : 0.f;     // (4 + latent index: the same offset in both layouts)
     float acc = 0.f;
-    if (i < HEAD + H) { const int j = i - HEAD; for (int q = 0; q < PO; ++q) acc += src[sW1 + c * IN + HEAD + q] * pW4[q * H + j]; }
-    else if (i == HEAD + H) { for (int q = 0; q < PO; ++q) acc += src[sW1 + c * IN + HEAD + q] * pb4[q]; }
+    if (i < HEAD + H) { const int j = i - HEAD; if (j < Hr) for (int q = 0; q < PO; ++q) acc += src[sW1 + c * INr + HEADr + q] * pW4[q * Hr + j]; }
+    else if (i == HEAD + H) { for (int q = 0; q < PO; ++q) acc += src[sW1 + c * INr + HEADr + q] * pb4[q]; }
     return acc;
   };
+  auto W4r = [&](int j, int i) -> float { return (j < OUTr && i < Hr) ? src[sW4 + j * Hr + i] : 0.f; };    // linear4.weight[j][i]
   const int ob1 = INF * H, oW2 = ob1 + H, ob2 = oW2 + H * H, oW4 = ob2 + H, ob4 = oW4 + H * OUTP, tt = ob4 + OUTP;
   for (int e = threadIdx.x; e < (int)fam.t_sz[f]; e += blockDim.x) {
     float v = 0.f;
     if (e < ob1) { int i = e / H, j = e % H; v = w1f(j, i); }
-    else if (e < oW2) v = src[sb1 + (e - ob1)];
-    else if (e < ob2) { int q = e - oW2, i = q / H, j = q % H; v = src[sW2 + j * H + i]; }
-    else if (e < oW4) v = src[sb2 + (e - ob2)];
-    else if (e < ob4) { int q = e - oW4, i = q / OUTP, j = q % OUTP; v = j < OUT ? src[sW4 + j * H + i] : 0.f; }
-    else if (e < tt) { int j = e - ob4; v = j < OUT ? src[sb4 + j] : 0.f; }
+    else if (e < oW2) v = b1r(e - ob1);
+    else if (e < ob2) { int q = e - oW2, i = q / H, j = q % H; v = W2r(j, i); }
+    else if (e < oW4) v = b2r(e - ob2);
+    else if (e < ob4) { int q = e - oW4, i = q / OUTP, j = q % OUTP; v = W4r(j, i); }
+    else if (e < tt) { int j = e - ob4; v = j < OUTr ? src[sb4 + j] : 0.f; }
     t[e] = v;
   }
   const int nW2 = OUTP * H, nW1 = nW2 + H * H, nt = nW1 + H * INFP;
   for (int e = threadIdx.x; e < (int)fam.n_sz[f]; e += blockDim.x) {
     float v = 0.f;
-    if (e < nW2) { int j = e / H, i = e % H; v = j < OUT ? src[sW4 + j * H + i] : 0.f; }
-    else if (e < nW1) v = src[sW2 + (e - nW2)];
+    if (e < nW2) { int j = e / H, i = e % H; v = W4r(j, i); }
+    else if (e < nW1) { int q = e - nW2; v = W2r(q / H, q % H); }
     else if (e < nt) { int q = e - nW1, j = q / INFP, i = q % INFP; v = i < INF ? w1f(j, i) : 0.f; }
     else { int q = e - nt, g = q / (4 * H), j = (q % (4 * H)) / 4, i = 4 * g + (q & 3); v = (g < (INF + 3) / 4 && i < INF) ? w1f(j, i) : 0.f; }   // W1x
     n[e] = v;

@@ -268,6 +268,12 @@ def main():
         ('c300_b1_K10_d20_multi', 300, 1, 10, 20, 10, True, 10, 1.0),       # BASELINE config 5 shape
         ('c14_b2_K15_d10_multi', 14, 2, 15, 10, 10, True, 11, 1.0),         # the reference's own run configuration (main.py:209-213)
         ('c14_b2_K30_d10_single', 14, 2, 30, 10, 10, False, 12, 1.0),       # the reference's constructor defaults (main.py:108)
+        # widths between the compiled kernels': the HIP path runs them zero-padded on the next wider kernel ("maybe also try more or
+        # less hidden dim", main.py:215); odd widths included
+        ('c14_b2_K3_d16_h8_multi', 14, 2, 3, 16, 8, True, 13, 1.0),
+        ('c14_b2_K4_d7_h5_single', 14, 2, 4, 7, 5, False, 14, 1.0),
+        ('c30_b2_K2_d20_h6_multi', 30, 2, 2, 20, 6, True, 15, 1.0),
+        ('c14_b2_K4_d3_h10_multi_lowload', 14, 2, 4, 3, 10, True, 16, 0.2),
     ]
     for c in cases:
         run_case(ref, synth, *c)

@@ -861,7 +861,7 @@ def test_error_behaviour_on_device():
         oc, og = cpu_model(bu.cpu(), li.cpu(), ge.cpu()), gpu_model(bu, li, ge)
     assert oc[0].device.type == 'cpu' and torch.equal(oc[0], og[0].cpu()) and torch.equal(oc[2], og[2].cpu())
     with pytest.raises(amd.GNSError):
-        amd.GNS(12, 10, 2, 0.9, True).cuda()(bu, li, ge)   # no kernel compiled for latent_dim 12
+        amd.GNS(24, 10, 2, 0.9, True).cuda()(bu, li, ge)   # no compiled kernel holds latent_dim 24 (narrower models run zero-padded)
 
 
 def test_smoke_entry():

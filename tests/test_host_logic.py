@@ -132,7 +132,9 @@ def test_workspace_sizes_are_consistent():
     assert b.value > a.value > 0 and c.value > 0
     assert b.value < 3 * 2**30      # K+1 saved states + K hidden-sum sets of 16384 case118 grids stay below 3 GiB
     assert lib.gns_config_supported(ctypes.byref(cfg)) == 1
-    assert lib.gns_config_supported(ctypes.byref(_lib.GnsConfig(118, 186, 54, 4, 12, 10, 1, 0.9))) == 0
+    assert lib.gns_config_supported(ctypes.byref(_lib.GnsConfig(118, 186, 54, 4, 12, 10, 1, 0.9))) == 1     # runs zero-padded on the (20, 10) kernels
+    assert lib.gns_config_supported(ctypes.byref(_lib.GnsConfig(118, 186, 54, 4, 24, 10, 1, 0.9))) == 0
+    assert lib.gns_config_supported(ctypes.byref(_lib.GnsConfig(118, 186, 54, 4, 10, 12, 1, 0.9))) == 0
 
 
 def test_synthetic_grids_follow_the_reference_layout_and_ranges():
