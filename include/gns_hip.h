@@ -56,9 +56,9 @@ const char* gns_version(void);
  * params buffer (GNS/main.py:113-134).  */
 int gns_param_count(const gns_config* cfg, int64_t* count);
 
-/* 1 if a compiled kernel holds this model, else 0.  Kernels are compiled for (latent_dim, hidden_dim) = (20, 10) and (10, 10), both
- * phi modes; a narrower model (any latent_dim <= 20, hidden_dim <= 10, e.g. the "less hidden dim" of main.py:215) runs on the next wider
- * pair zero-padded - same outputs, same gradients, delivered in the MODEL's flat layout (gns_param_count floats). */
+/* 1 if a compiled kernel holds this model, else 0.  Kernels are compiled for (latent_dim, hidden_dim) = (20, 10), (10, 10) and (20, 14),
+ * both phi modes; a narrower model (any latent_dim <= 20, hidden_dim <= 14: the "more or less hidden dim" of main.py:215) runs on the
+ * smallest pair that holds it zero-padded - same outputs, same gradients, delivered in the MODEL's flat layout (gns_param_count floats). */
 int gns_config_supported(const gns_config* cfg);
 
 /* Host-side topology preparation (replaces the per-call index construction of main.py:35-36,85-86,144,153):

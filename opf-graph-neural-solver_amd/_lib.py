@@ -5,7 +5,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-GNS_ERRORS = {1: 'GNS_EINVAL (bad argument)', 2: 'GNS_EUNSUPPORTED (no compiled kernel holds this model: latent_dim <= 20, hidden_dim <= 10, K <= 64; narrower models run zero-padded on the next wider kernel)',
+GNS_ERRORS = {1: 'GNS_EINVAL (bad argument)', 2: 'GNS_EUNSUPPORTED (no compiled kernel holds this model: latent_dim <= 20, hidden_dim <= 14, K <= 64; narrower models run zero-padded on the next wider kernel)',
               3: 'GNS_ETOPOLOGY (bus id out of range or not a valid line index)', 4: 'GNS_ESIZE (buffer too small)',
               5: 'GNS_ELAUNCH (HIP launch error)'}
 

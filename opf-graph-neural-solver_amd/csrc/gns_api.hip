@@ -162,7 +162,9 @@ static int lane_team(int64_t Bt) {
 // The split backward (bwd_variant 4) runs the three-phi models on the matrix-pipe engine; everything else keeps the persistent kernel.
 static bool use_split_backward(const gns_config* c) {
   const GnsTuning& T = tuning();
-  return T.bwd_variant == 4 && device().split_ready && T.dw_mfma && gns_bwds_supported(c->latent_dim, c->hidden_dim, c->multiple_phi);
+  if (!device().split_ready || !gns_bwds_supported(c->latent_dim, c->hidden_dim, c->multiple_phi)) return false;
+  if (!gns_backward_persistent_supported(c->latent_dim, c->hidden_dim)) return true;      // the only lane-per-grid backward of this pair
+  return T.bwd_variant == 4 && T.dw_mfma;
 }
 
 // Which mapping runs a training-mode forward and its backward.  Evaluated identically by gns_forward and gns_backward:

@@ -1015,6 +1015,13 @@ static int launch_backward_t(const GnsBwdArgs& A, int blocks, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? GNS_OK : GNS_ELAUNCH;
 }
 
+int gns_backward_persistent_supported(int d, int h) {
+#define GNS_CASE(DD, HH) if (d == DD && h == HH) return 1;
+  GNS_FOR_EACH_DIMS_PERSISTENT(GNS_CASE)
+#undef GNS_CASE
+  return 0;
+}
+
 int gns_launch_backward(int d, int h, int multi, int mfma, int variant, const GnsBwdArgs& A, int blocks, hipStream_t st) {
 #define GNS_CASE(DD, HH)                                                                                      \
   if (d == DD && h == HH) {                                                                                   \
@@ -1023,7 +1030,7 @@ int gns_launch_backward(int d, int h, int multi, int mfma, int variant, const Gn
     if (mfma) return multi ? launch_backward_t<DD, HH, true, true, 1>(A, blocks, st) : launch_backward_t<DD, HH, false, true, 1>(A, blocks, st);   \
     return multi ? launch_backward_t<DD, HH, true, false, 1>(A, blocks, st) : launch_backward_t<DD, HH, false, false, 1>(A, blocks, st);          \
   }
-  GNS_FOR_EACH_DIMS(GNS_CASE)
+  GNS_FOR_EACH_DIMS_PERSISTENT(GNS_CASE)
 #undef GNS_CASE
   return GNS_EUNSUPPORTED;
 }

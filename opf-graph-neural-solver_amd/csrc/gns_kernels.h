@@ -21,8 +21,11 @@ static inline int gns_fwd_plane2_fits(int N, int team) {
   return team == 1 && 2 * (size_t)N * GNS_LANES * 8 + GNS_FWD_RED_BYTES <= (size_t)GNS_FWD_DYN_LDS_MAX;
 }
 
-// (latent_dim, hidden_dim) pairs with compiled kernels
-#define GNS_FOR_EACH_DIMS(X) X(20, 10) X(10, 10)
+// (latent_dim, hidden_dim) pairs with compiled kernels (a narrower model runs zero-padded on the smallest pair that holds it)
+#define GNS_FOR_EACH_DIMS(X) X(20, 14) X(20, 10) X(10, 10)
+// ... of the persistent lane-per-grid backward kernels (bwd_variant 1-3, the packed-FMA engine): their record windows are laid out for
+// hidden_dim 10; wider pairs always take the split backward or the grid-per-workgroup pair
+#define GNS_FOR_EACH_DIMS_PERSISTENT(X) X(20, 10) X(10, 10)
 
 template <int D, int H, bool MULTI>
 struct GnsDims {
@@ -74,6 +77,7 @@ struct GnsBwdArgs {
 };
 
 int gns_launch_backward(int d, int h, int multi, int mfma, int variant, const GnsBwdArgs& A, int blocks, hipStream_t st);
+int gns_backward_persistent_supported(int d, int h);
 int gns_launch_reduce(const float* slab, float* part, float* tmp, const float* flat, float* grad, long long nslab, long long sf,
                       const GnsFamilies& fam, int K, int D, int H, hipStream_t st, long long stride = 0);   // stride (floats) between the slabs read; 0: sf
 int gns_launch_forward(int d, int h, int multi, const GnsFwdArgs& A, int threads, hipStream_t st);

@@ -274,6 +274,10 @@ def main():
         ('c14_b2_K4_d7_h5_single', 14, 2, 4, 7, 5, False, 14, 1.0),
         ('c30_b2_K2_d20_h6_multi', 30, 2, 2, 20, 6, True, 15, 1.0),
         ('c14_b2_K4_d3_h10_multi_lowload', 14, 2, 4, 3, 10, True, 16, 0.2),
+        # "more hidden dim": the (20, 14) kernels, exactly and zero-padded
+        ('c14_b2_K3_d20_h14_multi', 14, 2, 3, 20, 14, True, 17, 1.0),
+        ('c14_b2_K4_d10_h12_single', 14, 2, 4, 10, 12, False, 18, 1.0),
+        ('c30_b2_K2_d12_h11_multi', 30, 2, 2, 12, 11, True, 19, 1.0),
     ]
     for c in cases:
         run_case(ref, synth, *c)

@@ -1069,3 +1069,36 @@ def test_split_backward_modes_agree_with_the_persistent_kernel(case, bt, d, K, m
             assert err < 5e-6, f'mode {mode}: {err:.2e} of max|grad|'
     finally:
         amd.set_option('bwd_variant', old[0]); amd.set_option('bwds_mode', old[1])
+
+
+@pytest.mark.parametrize('d,h,multi', [(13, 12, True), (6, 7, False), (20, 14, True)])
+def test_widths_between_the_compiled_kernels_on_ragged_batches_against_oracle(d, h, multi):
+    """A model narrower than a compiled (latent_dim, hidden_dim) pair runs on it zero-padded (gns_common.h, GnsFamilies): (13, 12) on the
+    (20, 14) kernels, (6, 7) on (10, 10); (20, 14) is a compiled pair itself.  130 case30 grids (three 64-grid groups, the last
+    ragged), default mapping selection, non-trivial upstream gradients: outputs of three grids and the summed gradient of all of
+    them against the CPU oracle; the gradient comes back in the MODEL's flat layout."""
+    import opf_graph_neural_solver_amd as amd
+    from oracle import gns_oracle as orc
+    K, bt = 3, 130
+    torch.manual_seed(11)
+    m = amd.GNS(d, h, K, 0.9, multi).cuda()
+    assert sum(p.numel() for p in m.parameters()) == m.flat_parameters().numel()
+    bu, li, ge = amd.synth.synth_grids(30, bt, seed=5, device='cuda')
+    gen = torch.Generator(device='cuda').manual_seed(2)
+    wt = torch.rand(bt, device='cuda', generator=gen) + 0.5
+    with torch.no_grad():
+        ev = m(bu, li, ge)
+    v, th, tot, last = m(bu, li, ge)
+    ((tot * wt).sum() / bt).backward()
+    grad = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).cpu()
+    flat = m.flat_parameters().detach().cpu()
+    g_o = torch.zeros_like(flat)
+    for b in range(bt):
+        f = flat.clone().requires_grad_(True)
+        o = orc.gns_forward(orc.unflatten_params(f, d, h, K, multi), bu[b].cpu(), li[b].cpu(), ge[b].cpu(), latent_dim=d, K=K, gamma=0.9, multiple_phi=multi)
+        (o[2] * float(wt[b]) / bt).backward()
+        g_o += f.grad
+        if b in (0, 64, 129):
+            for mine, ref, what in ((v[b], o[0], 'v'), (th[b], o[1], 'theta'), (tot[b], o[2], 'total'), (ev[0][b], o[0], 'v eval'), (ev[2][b], o[2], 'total eval')):
+                assert_close(mine.detach().cpu(), ref.detach(), REL, what=f'{what}[{b}]')
+    assert_close(grad, g_o, 5e-5, abs_floor=1e-7, what='grad_params')

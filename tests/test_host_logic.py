@@ -134,7 +134,8 @@ def test_workspace_sizes_are_consistent():
     assert lib.gns_config_supported(ctypes.byref(cfg)) == 1
     assert lib.gns_config_supported(ctypes.byref(_lib.GnsConfig(118, 186, 54, 4, 12, 10, 1, 0.9))) == 1     # runs zero-padded on the (20, 10) kernels
     assert lib.gns_config_supported(ctypes.byref(_lib.GnsConfig(118, 186, 54, 4, 24, 10, 1, 0.9))) == 0
-    assert lib.gns_config_supported(ctypes.byref(_lib.GnsConfig(118, 186, 54, 4, 10, 12, 1, 0.9))) == 0
+    assert lib.gns_config_supported(ctypes.byref(_lib.GnsConfig(118, 186, 54, 4, 10, 12, 1, 0.9))) == 1     # zero-padded on (20, 14)
+    assert lib.gns_config_supported(ctypes.byref(_lib.GnsConfig(118, 186, 54, 4, 10, 15, 1, 0.9))) == 0
 
 
 def test_synthetic_grids_follow_the_reference_layout_and_ranges():
