@@ -11,7 +11,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ._lib import GNS_ERRORS, GnsConfig, load_library
+from ._lib import GNS_ERRORS, GnsConfig, get_option, load_library
 
 
 class GNSError(RuntimeError):
@@ -161,6 +161,12 @@ class _GNSFunction(torch.autograd.Function):
                                     ge.data_ptr(), ctx.Bt, None if ctx.packed is None else ctx.packed.data_ptr(), ctx.ws.data_ptr(),
                                     ctx.ws.numel(), ptr(keep[0]), ptr(keep[1]), ptr(keep[2]), ptr(keep[3]), grad.data_ptr(),
                                     bws.data_ptr(), bws.numel(), stream), 'gns_backward')
+        # The persistent backward kernels (bwd_variant 1-3 or the packed-FMA engine: opt-ins) run in teams too; one that gave up leaves
+        # NaN in the first gradient element (gns_backward.hip).  The default split backward has no teams and is not checked.
+        if ctx.team_status and not torch.cuda.is_current_stream_capturing() and (get_option('bwd_variant') != 4 or get_option('dw_mfma') == 0):
+            if bool(torch.isnan(grad[0])):
+                raise GNSError('a team of workgroups gave up at a barrier of the backward kernel: no gradient is delivered '
+                               '(opf_graph_neural_solver_amd.set_option("team", 1) or the default bwd_variant 4 run without teams)')
         pdev = ctx.params[0].device
         if pdev != dev:
             grad = grad.to(pdev)                          # CPU-resident model: 59 KB back to the host, like the reference's .grad
