@@ -251,7 +251,21 @@ __device__ __forceinline__ f2 lrelu2(f2 z) { return __builtin_elementwise_max(z,
 template <int I, int HP>
 __device__ __forceinline__ float lane_of(const f2 (&a)[HP]) { return (I & 1) ? a[I / 2].y : a[I / 2].x; }
 // derivative of LeakyReLU from its OUTPUT (sign-preserving): 1 where a > 0 else slope
-__device__ __forceinline__ f2 dlrelu2(f2 a) { return f2{a.x > 0.f ? 1.f : GNS_LEAKY, a.y > 0.f ? 1.f : GNS_LEAKY}; }
+#ifndef GNS_DLRELU_CLAMP
+#define GNS_DLRELU_CLAMP 1
+#endif
+__device__ __forceinline__ f2 dlrelu2(f2 a) {
+#if GNS_DLRELU_CLAMP
+  // Two packed instructions instead of two compares and two selects.  t = clamp(a * 2^126) - the clamp bit of the packed multiply
+  // saturates to [0, 1] - is 1 for every normal a > 0 and 0 for a <= 0; t * 0.99f + 0.01f (one rounding) is then exactly 1.0f or
+  // exactly 0.01f, so every gradient keeps its bits.  (A subnormal a > 0, below 1.2e-38, would get a slope between the two.)
+  f2 t;
+  asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(t) : "v"(a), "s"(splat(0x1p126f)));
+  return __builtin_elementwise_fma(t, splat(1.f - GNS_LEAKY), splat(GNS_LEAKY));
+#else
+  return f2{a.x > 0.f ? 1.f : GNS_LEAKY, a.y > 0.f ? 1.f : GNS_LEAKY};
+#endif
+}
 
 // LearningBlock forward (GNS/main.py:25-31) from the T-stream:
 //   W1t[IN][H] b1[H] W2t[H][H] b2[H] W4t[H][OUTP] b4[OUTP]
