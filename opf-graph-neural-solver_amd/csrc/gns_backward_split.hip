@@ -29,6 +29,9 @@ typedef int gns_i8v __attribute__((ext_vector_type(8)));   // one line record of
 #define GNS_BWDS_WPE 2          // waves per SIMD the sweep kernels are compiled for.  Measured (case118 x 16384): 3 (168 registers, 12 bus
                                 // chunks per group) is 8 % SLOWER than 2 - the sweeps are bound by the rows they stream, not by latency
 #endif
+#ifndef GNS_BWDS_FRESH_INPUTS
+#define GNS_BWDS_FRESH_INPUTS 1   // 0 (diagnostic): the nets of a bus share their broadcast input pairs (see gns_bwds_sweep_kernel)
+#endif
 #define GNS_BWDS_PHYS_THREADS (GNS_BWDS_PHYS_WAVES * 64)
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -663,20 +666,28 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GNS_BWD
       xs[XL - 1] = f2{(float)(p1 - p0), 1.f};             // deg, and the 1 whose column of dW1 is db1
       f2 gS[H / 2];                                       // adjoint of the hidden-vector sum: what every line ending at n receives
       const float g3v = is_gen[n] ? 0.f : a0.x;
+      // Every net of this bus broadcasts the same inputs into its first layer.  Seen as ONE value, a broadcast pair is built once, in
+      // registers of its own, and kept for the whole bus (80 v_mov and 40 VGPRs for the latent vector alone); re-defined before each
+      // net (an empty asm, no instruction), it is local to the net and folds into the op_sel bits of its packed FMAs.
+      auto fresh = [&]() {
+#if GNS_BWDS_FRESH_INPUTS
+        pin_all(xs);
+#endif
+      };
       if constexpr (MULTI) {
-        if constexpr (HAS_M) { if (!lastk) { lm.template bus<false, STEP0>(A, rec, lane, g, n, 0.f, xs, macc, xsum, gS); pm.template bus<STEP0>(A, rec, lane, xs, gS, macc, p0, p1, row_ein); } }
-        if constexpr (HAS_T) { lt.template bus<false, STEP0>(A, rec, lane, g, n, a0.y, xs, macc, xsum, gS); pt.template bus<STEP0>(A, rec, lane, xs, gS, macc, p0, p1, row_ein); }
+        if constexpr (HAS_M) { if (!lastk) { fresh(); lm.template bus<false, STEP0>(A, rec, lane, g, n, 0.f, xs, macc, xsum, gS); fresh(); pm.template bus<STEP0>(A, rec, lane, xs, gS, macc, p0, p1, row_ein); } }
+        if constexpr (HAS_T) { fresh(); lt.template bus<false, STEP0>(A, rec, lane, g, n, a0.y, xs, macc, xsum, gS); fresh(); pt.template bus<STEP0>(A, rec, lane, xs, gS, macc, p0, p1, row_ein); }
         // v moves only on buses without a generator (main.py:184-186): on a generator bus the upstream of L_v is exactly zero, and with
         // it every adjoint and every weight-gradient term of L_v and of phi_v over the lines ending there - the bus is skipped (the
         // topology is the same for all 64 grids of the wave, so the branch is uniform).  46 % of case118's buses carry a generator.
-        if constexpr (HAS_V) { if (!is_gen[n]) { lv.template bus<false, STEP0>(A, rec, lane, g, n, g3v, xs, macc, xsum, gS); pv.template bus<STEP0>(A, rec, lane, xs, gS, macc, p0, p1, row_ein); } }
+        if constexpr (HAS_V) { if (!is_gen[n]) { fresh(); lv.template bus<false, STEP0>(A, rec, lane, g, n, g3v, xs, macc, xsum, gS); fresh(); pv.template bus<STEP0>(A, rec, lane, xs, gS, macc, p0, p1, row_ein); } }
       } else {
 #pragma unroll
         for (int j = 0; j < H / 2; ++j) gS[j] = f2{0.f, 0.f};
-        if (!lastk) lm.template bus<true, STEP0>(A, rec, lane, g, n, 0.f, xs, macc, xsum, gS);
-        lt.template bus<true, STEP0>(A, rec, lane, g, n, a0.y, xs, macc, xsum, gS);
-        if (!is_gen[n]) lv.template bus<true, STEP0>(A, rec, lane, g, n, g3v, xs, macc, xsum, gS);     // (a generator bus: L_v's upstream is zero, see above)
-        pm.template bus<STEP0>(A, rec, lane, xs, gS, macc, p0, p1, row_ein);
+        if (!lastk) { fresh(); lm.template bus<true, STEP0>(A, rec, lane, g, n, 0.f, xs, macc, xsum, gS); }
+        fresh(); lt.template bus<true, STEP0>(A, rec, lane, g, n, a0.y, xs, macc, xsum, gS);
+        if (!is_gen[n]) { fresh(); lv.template bus<true, STEP0>(A, rec, lane, g, n, g3v, xs, macc, xsum, gS); }     // (a generator bus: L_v's upstream is zero, see above)
+        fresh(); pm.template bus<STEP0>(A, rec, lane, xs, gS, macc, p0, p1, row_ein);
       }
       if constexpr (!step0) {
         *row_ptr(A.adj, ar + 1 + SLOT, lane) = xsum;
