@@ -77,6 +77,16 @@ class _Topology:
         return t
 
 
+POISON_WORKSPACES = False     # test hook: workspaces are handed to the library filled with 0xFF bytes (NaN as floats) instead of
+                              # uninitialised, so that a kernel reading a word nothing wrote shows up as NaN instead of by chance
+
+
+def _workspace(nbytes, dev):
+    if POISON_WORKSPACES:
+        return torch.full((nbytes,), 0xFF, dtype=torch.uint8, device=dev)
+    return torch.empty(nbytes, dtype=torch.uint8, device=dev)
+
+
 def _raise_if_team_failed(lib, cfg, Bt, ws, save_state, dev):
     st = ctypes.c_int()
     with torch.cuda.device(dev):
@@ -100,7 +110,7 @@ class _GNSFunction(torch.autograd.Function):
         fwd_b, bwd_b = ctypes.c_size_t(), ctypes.c_size_t()
         _check(lib.gns_workspace_bytes(ctypes.byref(cfg), Bt, int(need_grad), ctypes.byref(fwd_b), ctypes.byref(bwd_b)),
                'gns_workspace_bytes')
-        ws = torch.empty(fwd_b.value, dtype=torch.uint8, device=dev)
+        ws = _workspace(fwd_b.value, dev)
         v = torch.empty((Bt, N), dtype=torch.float32, device=dev)
         theta = torch.empty_like(v)
         total = torch.empty(Bt, dtype=torch.float32, device=dev)
@@ -148,7 +158,7 @@ class _GNSFunction(torch.autograd.Function):
         if ctx.team_status and not torch.cuda.is_current_stream_capturing():     # (the check synchronises: not inside a graph capture)
             _raise_if_team_failed(lib, ctx.cfg, ctx.Bt, ctx.ws, 1, dev)
         grad = torch.zeros_like(flat)
-        bws = torch.empty(ctx.bwd_bytes, dtype=torch.uint8, device=dev)
+        bws = _workspace(ctx.bwd_bytes, dev)
 
         def ptr(t):
             return None if t is None else t.contiguous().data_ptr()

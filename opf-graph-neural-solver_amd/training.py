@@ -9,7 +9,7 @@ import torch
 import torch.distributed as tdist
 
 from . import dist as gdist
-from .gns import get_BLG
+from .gns import GNSError, get_BLG
 
 
 def checkpoint_name(case_nr, K, latent_dim, hidden_dim, multiple_phi, optimizer_name):
@@ -207,22 +207,30 @@ class GraphedStep:
         snap_p = flat.clone()
         snap_o = None if not optimizer.inner.state else {k: (v.clone() if torch.is_tensor(v) else v) for k, v in optimizer.inner.state[optimizer._flat].items()}
         snap_dev = None if optimizer._dev_state is None else optimizer._dev_state.clone()
+
+        def restore():
+            with torch.no_grad():
+                flat.copy_(snap_p)
+                st = optimizer.inner.state[optimizer._flat]
+                if snap_o is None:
+                    st['exp_avg'].zero_(); st['exp_avg_sq'].zero_(); optimizer._dev_state.zero_()
+                else:
+                    st['exp_avg'].copy_(snap_o['exp_avg']); st['exp_avg_sq'].copy_(snap_o['exp_avg_sq'])
+                    optimizer._dev_state.copy_(snap_dev) if snap_dev is not None else optimizer._dev_state.__setitem__(0, float(snap_o['step']))
+            torch.autograd.graph.increment_version(flat)
+
         side = torch.cuda.Stream(dev)
+        self._stream = side
         side.wait_stream(torch.cuda.current_stream(dev))
+        refs = []
         with torch.cuda.stream(side):
             optimizer.zero_grad(set_to_none=True)
-            train_step(model, optimizer, *self.static)            # eager warm-up (full topology check included)
+            for _ in range(2):                                    # eager warm-up (full topology check included); the parameters after
+                train_step(model, optimizer, *self.static)        # each step are what the first two replays must reproduce (below)
+                refs.append(flat.detach().clone())
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        with torch.no_grad():
-            flat.copy_(snap_p)
-            st = optimizer.inner.state[optimizer._flat]
-            if snap_o is None:
-                st['exp_avg'].zero_(); st['exp_avg_sq'].zero_(); optimizer._dev_state.zero_()
-            else:
-                st['exp_avg'].copy_(snap_o['exp_avg']); st['exp_avg_sq'].copy_(snap_o['exp_avg_sq'])
-                optimizer._dev_state.copy_(snap_dev) if snap_dev is not None else optimizer._dev_state.__setitem__(0, float(snap_o['step']))
-        torch.autograd.graph.increment_version(flat)
+        restore()
         saved = getattr(model, 'topology_check', None)
         model.topology_check = 'first'
         try:
@@ -236,6 +244,22 @@ class GraphedStep:
                 self.total, self.last = total.detach(), last_losses.detach().mean()
         finally:
             model.topology_check = saved
+        # Self-test.  ROCm 7's default way of replaying a graph (pre-built AQL packets, DEBUG_CLR_GRAPH_PACKET_CAPTURE) was measured
+        # to go wrong for this graph once the host has waited on the stream (hipStreamSynchronize / hipDeviceSynchronize) between
+        # replays: a step's forward right, its gradient not, NaN parameters a few steps later (tools/gpu_graph_replay_stream.py).  The
+        # package switches that path off at import (__init__.py) - which only takes if the HIP runtime was not initialised before.
+        # So: two replays, the host waiting on the stream before each, must leave exactly the parameters of the two eager warm-up
+        # steps; otherwise no GraphedStep is handed out (``fit`` then runs its steps eagerly).
+        ok = True
+        for ref in refs:
+            torch.cuda.current_stream(dev).synchronize()
+            self.graph.replay()
+            torch.cuda.synchronize(dev)
+            ok = ok and bool(torch.equal(flat.detach(), ref))
+        restore()
+        if not ok:
+            raise GNSError('a replayed HIP graph of the training step does not reproduce the eager step on this runtime (ROCm graph packet '
+                           'capture): set DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment before the first GPU call, or train without graph=True')
         self.replays = 0
 
     def run(self, buses, lines, generators):
@@ -308,7 +332,7 @@ def fit(model, all_buses, all_lines, all_generators, *, epochs=101, batch_size=1
         model.bind_dataset(all_buses, all_lines, all_generators)
         bound = True
     if graph is None:
-        graph = nr_samples >= batch_size and _graph_pays(model, optimizer, all_buses, all_lines, all_generators, batch_size)
+        graph = 'auto' if nr_samples >= batch_size and _graph_pays(model, optimizer, all_buses, all_lines, all_generators, batch_size) else False
     try:
         return _fit_loop(model, optimizer, all_buses, all_lines, all_generators, nr_samples, epochs, batch_size, optimizer_name,
                          case_nr, print_every, checkpoint_dir, log, best, bad, history, graph)
@@ -326,9 +350,15 @@ def _fit_loop(model, optimizer, all_buses, all_lines, all_generators, nr_samples
         finals = []
         for lo in range(0, nr_samples - batch_size + 1, batch_size):
             sl = slice(lo, lo + batch_size)
-            if graph:
-                if stepper is None:
+            if graph and stepper is None:
+                try:
                     stepper = GraphedStep(model, optimizer, all_buses[sl], all_lines[sl], all_generators[sl])
+                except GNSError as e:
+                    if graph is True:                # asked for explicitly: the caller hears about it
+                        raise
+                    log(f'captured training step not used: {e}')
+                    graph = False                    # 'auto': the eager loop computes the same thing
+            if graph:
                 _, last = stepper.run(all_buses[sl], all_lines[sl], all_generators[sl])
                 last = last.clone()                  # the next replay overwrites the graph's output
             else:

@@ -237,6 +237,39 @@ def test_graphed_step_replays_equal_eager_steps_at_the_reference_operating_point
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('wait', ['stream', 'device', 'none'])
+def test_graphed_step_replays_equal_eager_steps_when_the_host_waits_in_between(wait):
+    """Replays separated by a host-side wait on the stream (what any ``float(loss)`` / ``torch.cuda.synchronize()`` / checkpoint in a
+    training loop is).  With ROCm 7's default graph replay path (pre-built AQL packets) exactly this pattern computed wrong gradients
+    and NaN parameters a few steps later; the package switches that path off at import and GraphedStep verifies its first replays
+    (opf_graph_neural_solver_amd/__init__.py, training.GraphedStep).  Eight steps on alternating batches, bit for bit the eager loop's."""
+    bu, li, ge = amd.synth.synth_grids(14, 256, seed=3, device='cuda')
+
+    def run(graphed):
+        torch.manual_seed(0)
+        m = amd.GNS(20, 10, 4, 0.9, True).cuda()
+        opt = amd.training.make_optimizer(m, 'Adam', lr=1e-3)
+        st = None
+        for step in range(8):
+            sl = slice(128 * (step % 2), 128 * (step % 2) + 128)
+            if wait == 'stream':
+                torch.cuda.current_stream().synchronize()
+            elif wait == 'device':
+                torch.cuda.synchronize()
+            if graphed:
+                st = st or amd.training.GraphedStep(m, opt, bu[sl], li[sl], ge[sl])
+                st.run(bu[sl], li[sl], ge[sl])
+            else:
+                amd.training.train_step(m, opt, bu[sl], li[sl], ge[sl])
+        torch.cuda.synchronize()
+        return m.flat_parameters().detach().clone()
+
+    eager, graphed = run(False), run(True)
+    assert bool(torch.isfinite(graphed).all())
+    assert torch.equal(eager, graphed)
+
+
+@pytest.mark.gpu
 def test_fit_reads_a_bound_dataset_without_repacking_and_matches_per_call_packing():
     """fit() packs the resident data set once (GNS.bind_dataset); every 64-aligned batch of the epochs is read
     from that copy.  Same bits as the loop that packs each batch on every call."""
