@@ -29,6 +29,17 @@ typedef int gns_i8v __attribute__((ext_vector_type(8)));   // one line record of
 #define GNS_BWDS_WPE 2          // waves per SIMD the sweep kernels are compiled for.  Measured (case118 x 16384): 3 (168 registers, 12 bus
                                 // chunks per group) is 8 % SLOWER than 2 - the sweeps are bound by the rows they stream, not by latency
 #endif
+#ifndef GNS_BWDS_KEEP_SLOPES
+#define GNS_BWDS_KEEP_SLOPES 1    // the recomputation keeps LeakyReLU's slope of every hidden unit (two registers per pair and layer) and the
+#endif                            // backward multiplies by it instead of deriving it again from the activation: two packed instructions
+                                  // less per pair and layer on the dependent chain; 0 (diagnostic): derive again
+#if GNS_BWDS_KEEP_SLOPES
+#define GNS_SLOPES(sl) sl
+#define GNS_SLOPE_OF(sl, layer, act, u) sl[layer][u]
+#else
+#define GNS_SLOPES(sl) nullptr
+#define GNS_SLOPE_OF(sl, layer, act, u) dlrelu2(act[u])
+#endif
 #ifndef GNS_BWDS_FRESH_INPUTS
 #define GNS_BWDS_FRESH_INPUTS 1   // 0 (diagnostic): the nets of a bus share their broadcast input pairs (see gns_bwds_sweep_kernel)
 #endif
@@ -334,10 +345,11 @@ struct BwdsL : BwdsShape<D, H, MULTI> {
     load_pairs<H>(A.msg, ((((long long)A.k * A.G + g) * A.N + n) * C::NPHI + fphi) * C::HQ, lane, S);
     WFirst wf;
     f2 a1[H / 2], a2[H / 2], g2[H / 2], g1[H / 2];
+    f2 sl[2][H / 2];              // LeakyReLU's slopes at the hidden units, kept from the recomputation (GNS_BWDS_KEEP_SLOPES)
     using TL [[maybe_unused]] = TLay<LIN, H, OUTP>;   // the forward layout of the block: W1t b1 W2t b2 W4t b4
 #if GNS_BWDS_ONE_LAYOUT
     (void)wf;
-    mlp2_fwd<LIN, H>(ptl, xs, a1, a2);
+    mlp2_fwd<LIN, H>(ptl, xs, a1, a2, NoBG{}, NoLink{}, GNS_SLOPES(sl));
 #else
     using LKm = std::conditional_t<STEP0, NoLink, L2>; using LKs = std::conditional_t<STEP0, std::conditional_t<FOLD4, L0, NoLink>, std::conditional_t<FOLD4, L1, L2>>;
     if constexpr (STEP0) {
@@ -347,9 +359,9 @@ struct BwdsL : BwdsShape<D, H, MULTI> {
       const f2 (&st)[2] = reinterpret_cast<const f2 (&)[2]>(xs[0]);
       const f2 (&tl)[(LIN - 4 - D + 1) / 2] = reinterpret_cast<const f2 (&)[(LIN - 4 - D + 1) / 2]>(xs[SOFF]);
       phi_head<4, H>(ptl, st, u4);
-      phi_tail<LIN, H, 4 + D>(ptl, u4, tl, a1, a2);
+      phi_tail<LIN, H, 4 + D>(ptl, u4, tl, a1, a2, NoBG{}, NoLink{}, GNS_SLOPES(sl));
     } else {
-      mlp2_fwd<LIN, H>(ptl, xs, a1, a2, NoBG{}, L0{nullptr, nb, &wf});
+      mlp2_fwd<LIN, H>(ptl, xs, a1, a2, NoBG{}, L0{nullptr, nb, &wf}, GNS_SLOPES(sl));
     }
 #endif
     // output layer: g2 = (W4^T g3) * lrelu'(a2);  dW4 | db4 += g3 (x) [a2 | 1]
@@ -369,7 +381,7 @@ struct BwdsL : BwdsShape<D, H, MULTI> {
     }
 #endif
 #pragma unroll
-    for (int u = 0; u < H / 2; ++u) g2[u] = g2[u] * dlrelu2(a2[u]);
+    for (int u = 0; u < H / 2; ++u) g2[u] = g2[u] * GNS_SLOPE_OF(sl, 1, a2, u);
     if constexpr (FOLD4 || FOLDM) {                   // parked at columns 16..26 until the last dW1 window contracts them
       static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putB<SW>(rec, lane, 8 + j, a2[j]); });
       gws_putB<SW>(rec, lane, 8 + H / 2, f2{1.f, 0.f});
@@ -397,7 +409,7 @@ struct BwdsL : BwdsShape<D, H, MULTI> {
     bwd_rows<H, H>(nb + NL::oW2, g2, g1, NoBG{}, std::conditional_t<FOLD4, L2, NoLink>{&wf, nullptr, nullptr});
 #endif
 #pragma unroll
-    for (int u = 0; u < H / 2; ++u) g1[u] = g1[u] * dlrelu2(a1[u]);
+    for (int u = 0; u < H / 2; ++u) g1[u] = g1[u] * GNS_SLOPE_OF(sl, 0, a1, u);
     static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA<SW>(rec, lane, j, g2[j]); gws_putB<SW>(rec, lane, j, a1[j]); });
     gws_putB<SW>(rec, lane, H / 2, f2{1.f, 0.f});
     gws_w2r(); gws_pass<SW>(rec, lane, T2); gws_r2w();
@@ -509,19 +521,20 @@ struct BwdsPhi : BwdsShape<D, H, MULTI> {
       const f4 ea = *row_ptr(IN, row_ein + 3LL * p, lane), eb = *row_ptr(IN, row_ein + 3LL * p + 1, lane);
       const f2 xt[3] = {f2{ea.x, ea.y}, f2{ea.z, ea.w}, f2{eb.x, 0.f}};
       f2 a1[H / 2], a2[H / 2], g2[H / 2], g1[H / 2];
+      f2 sl[2][H / 2];
 #if GNS_BWDS_ONE_LAYOUT
-      phi_tail<PIN, H, D>(ptb, uh, xt, a1, a2);
+      phi_tail<PIN, H, D>(ptb, uh, xt, a1, a2, NoBG{}, NoLink{}, GNS_SLOPES(sl));
 #pragma unroll
-      for (int u = 0; u < H / 2; ++u) g2[u] = gS[u] * dlrelu2(a2[u]);
+      for (int u = 0; u < H / 2; ++u) g2[u] = gS[u] * GNS_SLOPE_OF(sl, 1, a2, u);
       bwd_rows_fwd_layout<H, H>(ptb + TLay2<PIN, H>::oW2, g2, g1);
 #else
-      phi_tail<PIN, H, D>(ptb, uh, xt, a1, a2, NoBG{}, L0{nullptr, pnb, &wf});
+      phi_tail<PIN, H, D>(ptb, uh, xt, a1, a2, NoBG{}, L0{nullptr, pnb, &wf}, GNS_SLOPES(sl));
 #pragma unroll
-      for (int u = 0; u < H / 2; ++u) g2[u] = gS[u] * dlrelu2(a2[u]);
+      for (int u = 0; u < H / 2; ++u) g2[u] = gS[u] * GNS_SLOPE_OF(sl, 1, a2, u);
       bwd_rows<H, H>(pnb, g2, g1, NoBG{}, L2{&wf, nullptr, nullptr});
 #endif
 #pragma unroll
-      for (int u = 0; u < H / 2; ++u) { g1[u] = g1[u] * dlrelu2(a1[u]); G1[u] += g1[u]; }
+      for (int u = 0; u < H / 2; ++u) { g1[u] = g1[u] * GNS_SLOPE_OF(sl, 0, a1, u); G1[u] += g1[u]; }
       constexpr int pw = WIDE ? 8 : 0;                // wide window: the line's pass contracts columns 16..31
       static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA<SW>(rec, lane, j, g1[j]); });
       gws_putB<SW>(rec, lane, pw + 0, xt[0]); gws_putB<SW>(rec, lane, pw + 1, xt[1]); gws_putB<SW>(rec, lane, pw + 2, f2{xt[2].x, 1.f});

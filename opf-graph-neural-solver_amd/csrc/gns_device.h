@@ -356,9 +356,14 @@ struct TLay2 {
   static constexpr int ob1 = IN * H, oW2 = ob1 + H, ob2 = oW2 + H * H, total = ob2 + H;
 };
 
-template <int IN, int H, class BG = NoBG, class LK = NoLink>
-__device__ __forceinline__ void mlp2_fwd(cfp blk, const f2 (&x)[(IN + 1) / 2], f2 (&a1)[H / 2], f2 (&a2)[H / 2], BG&& bg = BG{}, LK lk = LK{}) {
+template <int IN, int H, class BG = NoBG, class LK = NoLink, class SL = decltype(nullptr)>
+__device__ __forceinline__ void mlp2_fwd(cfp blk, const f2 (&x)[(IN + 1) / 2], f2 (&a1)[H / 2], f2 (&a2)[H / 2], BG&& bg = BG{}, LK lk = LK{}, SL sl = nullptr) {
   using B = TLay2<IN, H>;
+  constexpr bool KEEP = !std::is_same<SL, decltype(nullptr)>::value;      // see phi_tail
+  auto act = [&](f2 z, int layer, int j) {
+    if constexpr (KEEP) { const f2 k = dlrelu2(z); sl[layer][j] = k; return z * k; }
+    else return lrelu2(z);
+  };
   stream_pairs<B::total, cf16p>(blk, [&](auto w_, f2 s) {
     constexpr int w = decltype(w_)::value;
     if constexpr (w < B::ob1) {
@@ -367,14 +372,14 @@ __device__ __forceinline__ void mlp2_fwd(cfp blk, const f2 (&x)[(IN + 1) / 2], f
       a1[j] = (i == 0) ? s * xi : __builtin_elementwise_fma(s, xi, a1[j]);
     } else if constexpr (w < B::oW2) {
       constexpr int j = (w - B::ob1) / 2;
-      a1[j] = lrelu2(a1[j] + s);
+      a1[j] = act(a1[j] + s, 0, j);
     } else if constexpr (w < B::ob2) {
       constexpr int q = w - B::oW2, i = q / H, j = (q % H) / 2;
       const f2 xi = splat(lane_of<i>(a1));
       a2[j] = (i == 0) ? s * xi : __builtin_elementwise_fma(s, xi, a2[j]);
     } else {
       constexpr int j = (w - B::ob2) / 2;
-      a2[j] = lrelu2(a2[j] + s);
+      a2[j] = act(a2[j] + s, 1, j);
     }
   }, bg, lk);
   pin_all(a2);
@@ -393,9 +398,16 @@ __device__ __forceinline__ void phi_head(cfp blk, const f2 (&m)[D / 2], f2 (&u)[
   }, bg, lk);
   pin_all(u);
 }
-template <int IN, int H, int D, class BG = NoBG, class LK = NoLink>
-__device__ __forceinline__ void phi_tail(cfp blk, const f2 (&u)[H / 2], const f2 (&xt)[(IN - D + 1) / 2], f2 (&a1)[H / 2], f2 (&a2)[H / 2], BG&& bg = BG{}, LK lk = LK{}) {
+// SL (a pointer to f2[2][H / 2], or nullptr_t): also hand out LeakyReLU's slope at each hidden unit (1.0f or 0.01f), formed on the way
+// (z * slope(z) is bitwise max(z, 0.01 z) for every normal z) - a backward that keeps them multiplies instead of deriving them again
+template <int IN, int H, int D, class BG = NoBG, class LK = NoLink, class SL = decltype(nullptr)>
+__device__ __forceinline__ void phi_tail(cfp blk, const f2 (&u)[H / 2], const f2 (&xt)[(IN - D + 1) / 2], f2 (&a1)[H / 2], f2 (&a2)[H / 2], BG&& bg = BG{}, LK lk = LK{}, SL sl = nullptr) {
   using B = TLay2<IN, H>;
+  constexpr bool KEEP = !std::is_same<SL, decltype(nullptr)>::value;
+  auto act = [&](f2 z, int layer, int j) {
+    if constexpr (KEEP) { const f2 k = dlrelu2(z); sl[layer][j] = k; return z * k; }
+    else return lrelu2(z);
+  };
   constexpr int W0 = D * H;
 #pragma unroll
   for (int j = 0; j < H / 2; ++j) a1[j] = u[j];
@@ -407,14 +419,14 @@ __device__ __forceinline__ void phi_tail(cfp blk, const f2 (&u)[H / 2], const f2
       a1[j] = __builtin_elementwise_fma(s, xi, a1[j]);
     } else if constexpr (w < B::oW2) {
       constexpr int j = (w - B::ob1) / 2;
-      a1[j] = lrelu2(a1[j] + s);
+      a1[j] = act(a1[j] + s, 0, j);
     } else if constexpr (w < B::ob2) {
       constexpr int q = w - B::oW2, i = q / H, j = (q % H) / 2;
       const f2 xi = splat(lane_of<i>(a1));
       a2[j] = (i == 0) ? s * xi : __builtin_elementwise_fma(s, xi, a2[j]);
     } else {
       constexpr int j = (w - B::ob2) / 2;
-      a2[j] = lrelu2(a2[j] + s);
+      a2[j] = act(a2[j] + s, 1, j);
     }
   }, bg, lk);
   pin_all(a2);
