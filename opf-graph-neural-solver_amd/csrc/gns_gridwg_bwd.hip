@@ -20,6 +20,16 @@
 // delta_q carries no gradient (identically zero as a function of v, theta: main.py:64-76 vs :83,98-103).
 #include "gns_device.h"
 #include "gns_gridwg.h"
+#ifndef GNS_GWB_KEEP_SLOPES
+#define GNS_GWB_KEEP_SLOPES 1     // as GNS_BWDS_KEEP_SLOPES (gns_backward_split.hip): the slopes of the hidden units are kept from the recomputation
+#endif
+#if GNS_GWB_KEEP_SLOPES
+#define GWB_SLOPES(sl) sl
+#define GWB_SLOPE_OF(sl, layer, act, u) sl[layer][u]
+#else
+#define GWB_SLOPES(sl) nullptr
+#define GWB_SLOPE_OF(sl, layer, act, u) dlrelu2(act[u])
+#endif
 #include "gns_dw.h"
 
 namespace {
@@ -360,7 +370,8 @@ __global__ void __launch_bounds__(MAXT, MINW) gns_gw_backward_kernel(GnsGwBwdArg
                 }
                 f2 a1[H / 2], a2[H / 2], g2[H / 2], g1[H / 2];
                 // only the hidden activations are needed: the T-stream of a three-layer block starts with the two-layer layout
-                mlp2_fwd<LIN, H>(PT + A.t_off[NPHI + l] + koff * A.t_sz[NPHI + l], xs, a1, a2);
+                f2 sl[2][H / 2];       // LeakyReLU's slopes, kept from the recomputation (GNS_GWB_KEEP_SLOPES; gns_device.h, phi_tail)
+                mlp2_fwd<LIN, H>(PT + A.t_off[NPHI + l] + koff * A.t_sz[NPHI + l], xs, a1, a2, NoBG{}, NoLink{}, GWB_SLOPES(sl));
                 // ---- output layer: g2 = (W4^T g3) * lrelu'(a2);  dW4 | db4 = sum g3 (x) [a2 | 1]
                 if constexpr (l == 2) {
                   bwd_rows<OUTP, H>(nb, macc, g2);                                          // g3 = mbar_{k+1}: m += L_m (main.py:188)
@@ -369,7 +380,7 @@ __global__ void __launch_bounds__(MAXT, MINW) gns_gw_backward_kernel(GnsGwBwdArg
                   bwd_rows<2, H>(nb, g3s, g2);
                 }
 #pragma unroll
-                for (int u = 0; u < H / 2; ++u) g2[u] = g2[u] * dlrelu2(a2[u]);
+                for (int u = 0; u < H / 2; ++u) g2[u] = g2[u] * GWB_SLOPE_OF(sl, 1, a2, u);
                 static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putB(rec, lane, j, a2[j]); });
                 gws_putB(rec, lane, H / 2, f2{1.f, 0.f});
                 static_for<0, (OUTP + 11) / 12>([&](auto t_) {
@@ -388,7 +399,7 @@ __global__ void __launch_bounds__(MAXT, MINW) gns_gw_backward_kernel(GnsGwBwdArg
                 // ---- hidden layer: g1 = (W2^T g2) * lrelu'(a1);  dW2 | db2 = sum g2 (x) [a1 | 1]
                 bwd_rows<H, H>(nb + NL::oW2, g2, g1);
 #pragma unroll
-                for (int u = 0; u < H / 2; ++u) g1[u] = g1[u] * dlrelu2(a1[u]);
+                for (int u = 0; u < H / 2; ++u) g1[u] = g1[u] * GWB_SLOPE_OF(sl, 0, a1, u);
                 static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA(rec, lane, j, g2[j]); gws_putB(rec, lane, j, a1[j]); });
                 gws_putB(rec, lane, H / 2, f2{1.f, 0.f});
                 gws_w2r();
@@ -454,12 +465,13 @@ __global__ void __launch_bounds__(MAXT, MINW) gns_gw_backward_kernel(GnsGwBwdArg
 #pragma unroll
               for (int j = 0; j < H / 2; ++j) gh[j] = f2{0.f, 0.f};
             }
-            phi_tail<PIN, H, D>(PT + A.t_off[pf] + koff * A.t_sz[pf], uh, xt[ep], a1, a2);
+            f2 sl[2][H / 2];
+            phi_tail<PIN, H, D>(PT + A.t_off[pf] + koff * A.t_sz[pf], uh, xt[ep], a1, a2, NoBG{}, NoLink{}, GWB_SLOPES(sl));
 #pragma unroll
-            for (int u = 0; u < H / 2; ++u) g2[u] = gh[u] * dlrelu2(a2[u]);
+            for (int u = 0; u < H / 2; ++u) g2[u] = gh[u] * GWB_SLOPE_OF(sl, 1, a2, u);
             bwd_rows<H, H>(PN + A.n_off[pf] + koff * A.n_sz[pf], g2, g1);
 #pragma unroll
-            for (int u = 0; u < H / 2; ++u) g1[u] = g1[u] * dlrelu2(a1[u]);
+            for (int u = 0; u < H / 2; ++u) g1[u] = g1[u] * GWB_SLOPE_OF(sl, 0, a1, u);
             if (is_e[ep]) gb_write_row<H>(g1_l + (li + ep * WL) * H, g1);
             // phi' line columns of dW1, db1 and dW2, db2
             static_for<0, H / 2>([&](auto j_) { constexpr int j = decltype(j_)::value; gws_putA(rec, lane, j, g1[j]); });
