@@ -185,17 +185,26 @@ static int gw_train_pack(const gns_config* c, int64_t Bt) {
 }
 // Grids per workgroup of the evaluation-mode forward when it runs on the grid-per-workgroup kernel, 0 when the lane-per-grid
 // kernel runs it.  gns_workspace_bytes, gns_forward and gns_uses_packed_inputs must agree, so they all ask here.
-static int gw_eval_pack(const gns_config* c) {
+static int gw_eval_pack(const gns_config* c, int64_t Bt) {
   const GnsTuning& T = tuning();
   const int N = c->n_bus, E = c->n_line;
+  const int wpg = ((N > E ? N : E) + 63) / 64;
   int P = T.gw_pack;
   if (P <= 0) {                                   // auto: one workgroup per CU with as many grids as fit (all waves of a CU in the
     P = 1;                                        // same phase stream the same weights: 73 % scalar-cache hits against 55 %)
-    const int wpg = ((N > E ? N : E) + 63) / 64;
     for (int q = 2; q * wpg <= 12; ++q) if (gns_gw_supported(N, E, c->latent_dim, c->hidden_dim, c->multiple_phi, q)) P = q;
   }
   const bool can = device().gw_ready && gns_gw_supported(N, E, c->latent_dim, c->hidden_dim, c->multiple_phi, P);
-  const bool want = T.fwd_mapping == 2 || (T.fwd_mapping == 0 && N >= 48);
+  bool want = T.fwd_mapping == 2 || (T.fwd_mapping == 0 && N >= 48);
+  if (T.fwd_mapping == 0 && want) {
+    // auto, by batch: once the lane-per-grid kernel fills the chip with one workgroup per 64-grid group it is the faster one (since it
+    // skips the v family on generator buses: case118 x 16384, 256 groups: 0.73 against 0.91 ms); a case too large to pack several
+    // grids into a workgroup hands over earlier (case300 x 8192, 128 groups on teams of two: 2.75 against 5.03 ms); small batches
+    // stay on chip (case30 x 4096, 64 groups: 0.12 against 0.18 ms).  Measured on MI355X, tools/gpu_time_eval.py.
+    const int64_t groups = (Bt + GNS_LANES - 1) / GNS_LANES;
+    const int ncu = device().ncu > 0 ? device().ncu : 256;
+    if (groups >= ncu || (P == 1 && wpg >= 5 && groups * 4 >= ncu)) want = false;
+  }
   return (can && want) ? P : 0;
 }
 
@@ -283,7 +292,7 @@ extern "C" int gns_workspace_bytes(const gns_config* cfg, int64_t Bt, int save_s
     if (bwd_bytes) *bwd_bytes = G.bwd_total;
     return GNS_OK;
   }
-  if (!save_state && gw_eval_pack(cfg) > 0) {                      // state on chip, inputs read in place: only the parameter streams
+  if (!save_state && gw_eval_pack(cfg, Bt) > 0) {                      // state on chip, inputs read in place: only the parameter streams
     if (fwd_bytes) *fwd_bytes = L.off_in;
     if (bwd_bytes) *bwd_bytes = 0;
     return GNS_OK;
@@ -307,7 +316,7 @@ extern "C" int gns_uses_packed_inputs(const gns_config* cfg, int64_t Bt, int sav
   const gns_config* model = cfg; gns_config kcfg_;
   if (!kernel_config(model, &kcfg_)) return 0;
   cfg = &kcfg_; (void)model;
-  return (save_state ? gw_train_pack(cfg, Bt) : gw_eval_pack(cfg)) > 0 ? 0 : 1;
+  return (save_state ? gw_train_pack(cfg, Bt) : gw_eval_pack(cfg, Bt)) > 0 ? 0 : 1;
 }
 
 // Did a team of workgroups give up at a barrier during the gns_forward that used this workspace?  (Teams: lane-per-grid kernels on a
@@ -326,7 +335,7 @@ extern "C" int gns_team_status_offset(const gns_config* cfg, int64_t Bt, int sav
   cfg = &kcfg_; (void)model;
   *offset = (size_t)-1;
   if (lane_team(Bt) <= 1) return GNS_OK;
-  if ((save_state ? gw_train_pack(cfg, Bt) : gw_eval_pack(cfg)) > 0) return GNS_OK;          // the grid-per-workgroup kernels have no teams
+  if ((save_state ? gw_train_pack(cfg, Bt) : gw_eval_pack(cfg, Bt)) > 0) return GNS_OK;          // the grid-per-workgroup kernels have no teams
   GnsFwdLayout L;
   gns_fwd_layout(cfg->n_bus, cfg->n_line, cfg->latent_dim, cfg->hidden_dim, cfg->K, cfg->multiple_phi, Bt, save_state, &L);
   *offset = L.off_team + GNS_TEAM_STATUS_WORD * 4;
@@ -343,7 +352,7 @@ extern "C" int gns_team_status(const gns_config* cfg, int64_t Bt, const void* fw
   cfg = &kcfg_; (void)model;
   *status = 0;
   if (lane_team(Bt) <= 1) return GNS_OK;
-  if ((save_state ? gw_train_pack(cfg, Bt) : gw_eval_pack(cfg)) > 0) return GNS_OK;          // the grid-per-workgroup kernels have no teams
+  if ((save_state ? gw_train_pack(cfg, Bt) : gw_eval_pack(cfg, Bt)) > 0) return GNS_OK;          // the grid-per-workgroup kernels have no teams
   GnsFwdLayout L;
   gns_fwd_layout(cfg->n_bus, cfg->n_line, cfg->latent_dim, cfg->hidden_dim, cfg->K, cfg->multiple_phi, Bt, save_state, &L);
   if (fwd_workspace_bytes < L.total) return GNS_ESIZE;
@@ -413,7 +422,7 @@ extern "C" int gns_forward(const gns_config* cfg, const void* topo_dev, const fl
   }
   GnsFwdLayout L;
   gns_fwd_layout(N, E, d, h, K, cfg->multiple_phi, Bt, save_state, &L);
-  if (workspace_bytes < ((!save_state && gw_eval_pack(cfg) > 0) ? L.off_in : L.total)) return GNS_ESIZE;
+  if (workspace_bytes < ((!save_state && gw_eval_pack(cfg, Bt) > 0) ? L.off_in : L.total)) return GNS_ESIZE;
   float* pt = (float*)(ws + L.off_pt);
   float* pn = (float*)(ws + L.off_pn);
   float* pin = (float*)(ws + L.off_in);
@@ -421,7 +430,7 @@ extern "C" int gns_forward(const gns_config* cfg, const void* topo_dev, const fl
   if (rc != GNS_OK) return rc;
   // Evaluation (nothing saved for a backward): the grid-per-workgroup mapping keeps the whole state on chip.
   {
-    const int P = save_state ? 0 : gw_eval_pack(cfg);
+    const int P = save_state ? 0 : gw_eval_pack(cfg, Bt);
     if (P > 0) {
       GnsGwFwdArgs G;
       std::memset(&G, 0, sizeof(G));

@@ -299,12 +299,26 @@ def test_full_size_batch_against_oracle_sample_and_properties(train_mapping):
         g_again = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
         assert torch.equal(v, v2) and torch.equal(th, th2) and torch.equal(tot, tot2) and torch.equal(g_all, g_again)
         # (c) a slice of the batch, alone, gives bitwise the same per-grid outputs
-        with torch.no_grad():
-            ve, the, tote, _ = m(bu, li, ge)
-            vs, ths, tots, _ = m(bu[100:229], li[100:229], ge[100:229])
-        # (evaluation runs the grid-per-workgroup kernel, training the lane-per-grid pair: each reproduces itself bitwise on
-        #  any batch composition, and the two agree to fp32 summation order)
-        assert torch.equal(vs, ve[100:229]) and torch.equal(ths, the[100:229]) and torch.equal(tots, tote[100:229])
+        # (the grid-per-workgroup kernel reproduces itself bitwise on any batch composition; which kernel an evaluation call takes by
+        #  itself depends on the batch - the full batch fills the chip on the lane-per-grid kernel, the slice stays on chip - and the
+        #  two agree to fp32 summation order)
+        old_fwd = amd.get_option('fwd_mapping')
+        try:
+            amd.set_option('fwd_mapping', 2)
+            with torch.no_grad():
+                ve, the, tote, _ = m(bu, li, ge)
+                vs, ths, tots, _ = m(bu[100:229], li[100:229], ge[100:229])
+            assert torch.equal(vs, ve[100:229]) and torch.equal(ths, the[100:229]) and torch.equal(tots, tote[100:229])
+            amd.set_option('fwd_mapping', 0)
+            with torch.no_grad():
+                va, tha, tota, _ = m(bu, li, ge)
+                vsa, thsa, totsa, _ = m(bu[100:229], li[100:229], ge[100:229])
+        finally:
+            amd.set_option('fwd_mapping', old_fwd)
+        assert_close(vsa.cpu(), va[100:229].cpu(), 2e-6, what='slice vs batch v (automatic mapping)')
+        assert_close(thsa.cpu(), tha[100:229].cpu(), 2e-6, what='slice vs batch theta (automatic mapping)')
+        assert_close(totsa.cpu(), tota[100:229].cpu(), 2e-6, what='slice vs batch total (automatic mapping)')
+        assert_close(va.cpu(), ve.cpu(), 2e-6, what='automatic vs grid-per-workgroup v')
         assert_close(ve.cpu(), v.detach().cpu(), 2e-6, what='eval vs train v')
         assert_close(the.cpu(), th.detach().cpu(), 2e-6, what='eval vs train theta')
         # training-mode slice: bitwise with the same number of workgroups per 64-grid group; a small batch alone is worked by
