@@ -572,7 +572,7 @@ int gwb_resident_t(int threads, size_t lds) {
 struct GwbShape { int recf, stgf; };
 GwbShape shape_of(int d, int h, int multi) {
 #define GNS_CASE(DD, HH) if (d == DD && h == HH) return multi ? GwbShape{GwBwdDims<DD, HH, true>::RECF, GwBwdDims<DD, HH, true>::STGF} : GwbShape{GwBwdDims<DD, HH, false>::RECF, GwBwdDims<DD, HH, false>::STGF};
-  GNS_FOR_EACH_DIMS(GNS_CASE)
+  GNS_FOR_EACH_DIMS_GWB(GNS_CASE)
 #undef GNS_CASE
   return GwbShape{-1, -1};
 }
@@ -585,7 +585,7 @@ int gns_gw_backward_init_device(void) {
   if (gwb_attr_t<DD, HH, true, 256, 2>() != GNS_OK || gwb_attr_t<DD, HH, false, 256, 2>() != GNS_OK ||              \
       gwb_attr_t<DD, HH, true, 512, 1>() != GNS_OK || gwb_attr_t<DD, HH, false, 512, 1>() != GNS_OK ||              \
       gwb_attr_t<DD, HH, true, 1024, 1>() != GNS_OK || gwb_attr_t<DD, HH, false, 1024, 1>() != GNS_OK) rc = GNS_ELAUNCH;
-  GNS_FOR_EACH_DIMS(GNS_CASE)
+  GNS_FOR_EACH_DIMS_GWB(GNS_CASE)
 #undef GNS_CASE
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
@@ -599,7 +599,6 @@ int gns_gw_backward_wpg(int N) { return (N + 63) / 64; }
 int gns_gw_backward_supported(int N, int E, int d, int h, int multi, int P) {
   const GwbShape S = shape_of(d, h, multi);
   if (S.recf < 0 || P < 1) return 0;
-  if (h != 10) return 0;      // this kernel's staged windows are laid out (and parity-tested) for hidden_dim 10: the wider pair trains on the lane-per-grid kernels
   const int WPG = gns_gw_backward_wpg(N);
   if (WPG * P > 16 || E > 2 * 64 * WPG) return 0;                       // at most two lines per lane
   const GwBwdLds L = gw_bwd_lds_layout(N, E, h, WPG, S.recf, S.stgf);
@@ -620,7 +619,7 @@ int gns_gw_backward_blocks(int N, int E, int d, int h, int multi, int P, long lo
     else if (threads <= 512) per_cu = multi ? gwb_resident_t<DD, HH, true, 512, 1>(threads, lds) : gwb_resident_t<DD, HH, false, 512, 1>(threads, lds);   \
     else per_cu = multi ? gwb_resident_t<DD, HH, true, 1024, 1>(threads, lds) : gwb_resident_t<DD, HH, false, 1024, 1>(threads, lds);                    \
   }
-  GNS_FOR_EACH_DIMS(GNS_CASE)
+  GNS_FOR_EACH_DIMS_GWB(GNS_CASE)
 #undef GNS_CASE
   const long long npacks = (Bt + P - 1) / P;
   const long long cap = (long long)(g_gwb_cus > 0 ? g_gwb_cus : 256) * per_cu;
@@ -643,7 +642,7 @@ int gns_gw_launch_backward(int d, int h, int multi, const GnsGwBwdArgs& A, int b
     return multi ? gwb_launch_t<DD, HH, true, 1024, 1>(A, blocks, threads, lds, st)                                \
                  : gwb_launch_t<DD, HH, false, 1024, 1>(A, blocks, threads, lds, st);                              \
   }
-  GNS_FOR_EACH_DIMS(GNS_CASE)
+  GNS_FOR_EACH_DIMS_GWB(GNS_CASE)
 #undef GNS_CASE
   return GNS_EUNSUPPORTED;
 }

@@ -26,6 +26,9 @@ static inline int gns_fwd_plane2_fits(int N, int team) {
 // ... of the persistent lane-per-grid backward kernels (bwd_variant 1-3, the packed-FMA engine): their record windows are laid out for
 // hidden_dim 10; wider pairs always take the split backward or the grid-per-workgroup pair
 #define GNS_FOR_EACH_DIMS_PERSISTENT(X) X(20, 10) X(10, 10)
+// ... and of the grid-per-workgroup backward (its staged windows too): a (20, 14) model evaluates on either mapping and trains on the
+// lane-per-grid forward + split backward
+#define GNS_FOR_EACH_DIMS_GWB(X) X(20, 10) X(10, 10)
 
 template <int D, int H, bool MULTI>
 struct GnsDims {
